@@ -1,0 +1,327 @@
+// extern "C" entry points of libaecf_hip.so (declared in include/aecf_hip.h).
+// Host-side orchestration only: validates the description, carves the caller's workspace and
+// enqueues the kernels on the caller's stream.  No allocation, no synchronisation, no exceptions.
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/aecf_hip.h"
+#include "aecf_kernels.h"
+
+using namespace aecf;
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+inline int esize(int dtype) { return dtype == AECF_BF16 ? 2 : 4; }
+
+struct FwdWs {
+    size_t qs, a_f32, a_hi, a_lo, obuf, total;
+};
+FwdWs fwd_layout(const aecf_pool_desc* d) {
+    FwdWs w;
+    const size_t E = d->embed_dim, es = esize(d->dtype);
+    size_t off = 0;
+    w.qs = off;    off = align_up(off + E * 4);
+    w.a_f32 = off; off = align_up(off + HPAD * E * 4);
+    w.a_hi = off;  off = align_up(off + HPAD * E * es);
+    w.a_lo = off;  off = align_up(off + HPAD * E * es);
+    w.obuf = off;  off = align_up(off + (size_t)d->batch * E * es);
+    w.total = off;
+    return w;
+}
+
+struct BwdWs {
+    size_t qs, a_f32, a_hi, a_lo, wvt, wot, dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, total;
+    int splits;
+    int64_t rows_per_split;
+};
+BwdWs bwd_layout(const aecf_pool_desc* d) {
+    BwdWs w;
+    const size_t E = d->embed_dim, es = esize(d->dtype);
+    const size_t B = (size_t)d->batch;
+    const int tiles = (int)(((E + 127) / 128) * ((E + 127) / 128));
+    int S = (512 + tiles - 1) / tiles;                  // ~2 workgroups per CU; slab bytes stay ~32 MB per matrix
+    const int64_t max_s = (int64_t)((B + 255) / 256);   // but at least 256 batch rows per split
+    if (S > max_s) S = (int)max_s;
+    if (S < 1) S = 1;
+    int64_t rps = (int64_t)((B + S - 1) / S);
+    rps = (rps + 31) / 32 * 32;
+    S = (int)((B + rps - 1) / rps);
+    w.splits = S;
+    w.rows_per_split = rps;
+    size_t off = 0;
+    w.qs = off;     off = align_up(off + E * 4);
+    w.a_f32 = off;  off = align_up(off + HPAD * E * 4);
+    w.a_hi = off;   off = align_up(off + HPAD * E * es);
+    w.a_lo = off;   off = align_up(off + HPAD * E * es);
+    w.wvt = off;    off = align_up(off + E * E * es);
+    w.wot = off;    off = align_up(off + E * E * es);
+    w.dobuf = off;  off = align_up(off + B * E * es);
+    w.dsbuf = off;  off = align_up(off + B * d->num_heads * d->modalities * 4);
+    w.slab_o = off; off = align_up(off + (size_t)S * E * E * 4);
+    w.slab_v = off; off = align_up(off + (size_t)S * E * E * 4);
+    w.cs_o = off;   off = align_up(off + (size_t)S * E * 4);
+    w.cs_v = off;   off = align_up(off + (size_t)S * E * 4);
+    w.u_slab = off; off = align_up(off + (size_t)S * HPAD * E * 4);
+    w.u = off;      off = align_up(off + HPAD * E * 4);
+    w.dqp = off;    off = align_up(off + E * 4);
+    w.total = off;
+    return w;
+}
+
+inline void mark(void** ev, int i, hipStream_t s) {
+    if (ev) (void)hipEventRecord((hipEvent_t)ev[i], s);
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? AECF_OK : AECF_ERR_LAUNCH; }
+
+MaskCfg make_mask_cfg(int mode, int min_active, float p, float tau, float eps, int L) {
+    MaskCfg c;
+    c.mode = mode;
+    c.min_active = min_active;
+    c.base_mask_prob = p;
+    c.entropy_target = tau;
+    c.eps = eps;
+    c.log_L = (float)log((double)L);
+    c.inv_L = (float)(1.0 / (double)L);
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aecf_abi_version(void) { return AECF_ABI_VERSION; }
+
+const char* aecf_status_string(int status) {
+    switch (status) {
+        case AECF_OK: return "ok";
+        case AECF_ERR_BAD_DIMS: return "bad dimensions";
+        case AECF_ERR_UNSUPPORTED:
+            return "configuration not supported by the HIP path (need 1<=M<=8, 1<=H<=16, E%64==0, head_dim%32==0 for "
+                   "bf16 / %16==0 for f32)";
+        case AECF_ERR_NULL_POINTER: return "required pointer is null";
+        case AECF_ERR_WORKSPACE: return "workspace too small";
+        case AECF_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown status";
+    }
+}
+
+const char* aecf_pool_stage_name(int backward, int stage) {
+    static const char* fwd[AECF_FWD_STAGES] = {"prep", "gate", "vproj", "outproj"};
+    static const char* bwd[AECF_BWD_STAGES] = {"prep", "dout", "dw_out", "dscore", "dx", "dw_v", "finalize"};
+    if (stage < 0) return nullptr;
+    if (!backward) return stage < AECF_FWD_STAGES ? fwd[stage] : nullptr;
+    return stage < AECF_BWD_STAGES ? bwd[stage] : nullptr;
+}
+
+int aecf_pool_check(const aecf_pool_desc* d) {
+    if (!d) return AECF_ERR_NULL_POINTER;
+    if (d->batch <= 0 || d->modalities <= 0 || d->embed_dim <= 0 || d->num_heads <= 0) return AECF_ERR_BAD_DIMS;
+    if (d->embed_dim % d->num_heads != 0) return AECF_ERR_BAD_DIMS;
+    if (d->dtype != AECF_BF16 && d->dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (d->modalities > 8 || d->num_heads > HPAD) return AECF_ERR_UNSUPPORTED;
+    if (d->embed_dim % 64 != 0) return AECF_ERR_UNSUPPORTED;
+    const int hd = d->embed_dim / d->num_heads;
+    if (hd % (d->dtype == AECF_BF16 ? 32 : 16) != 0) return AECF_ERR_UNSUPPORTED;
+    if (d->embed_dim > 1024) return AECF_ERR_UNSUPPORTED;
+    if (d->mask_mode < 0 || d->mask_mode > 2) return AECF_ERR_BAD_DIMS;
+    return AECF_OK;
+}
+
+size_t aecf_pool_fwd_workspace_bytes(const aecf_pool_desc* d) {
+    if (aecf_pool_check(d) != AECF_OK) return 0;
+    return fwd_layout(d).total;
+}
+
+size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d) {
+    if (aecf_pool_check(d) != AECF_OK) return 0;
+    return bwd_layout(d).total;
+}
+
+int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream) {
+    int st = aecf_pool_check(d);
+    if (st != AECF_OK) return st;
+    if (!a || !a->x || !a->query || !a->w_in || !a->w_out || !a->y || !a->attn_w || !a->saved_probs || !a->workspace)
+        return AECF_ERR_NULL_POINTER;
+    if (d->mask_mode == 1 && !a->uniforms) return AECF_ERR_NULL_POINTER;
+    const FwdWs L = fwd_layout(d);
+    if (a->workspace_bytes < L.total) return AECF_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)a->workspace;
+    const int E = d->embed_dim, H = d->num_heads, M = d->modalities, hd = E / H, es = esize(d->dtype);
+    float* qs = (float*)(ws + L.qs);
+    float* a_f32 = (float*)(ws + L.a_f32);
+    void* a_hi = ws + L.a_hi;
+    void* a_lo = ws + L.a_lo;
+    void* o = a->saved_o ? a->saved_o : (void*)(ws + L.obuf);
+    const float scale = sqrtf(1.0f / (float)hd);     // torch functional.py:6577 q * sqrt(1/head_dim)
+
+    void** ev = a->stage_events;
+    mark(ev, 0, s);
+    launch_prep_qs(d->dtype, a->w_in, a->b_in, a->query, qs, E, scale, s);
+    launch_prep_amat(d->dtype, a->w_in, qs, a_f32, a_hi, a_lo, E, H, s);
+    mark(ev, 1, s);
+
+    GateArgs g;
+    g.x = a->x; g.a_hi = a_hi; g.a_lo = a_lo; g.kpm = a->key_padding_mask; g.uniforms = a->uniforms;
+    g.probs = a->saved_probs; g.attn_w = a->attn_w; g.masked_w = a->masked_w; g.entropy = a->entropy;
+    g.mask_rate = a->mask_rate; g.B = d->batch; g.M = M; g.E = E; g.H = H;
+    g.mask = make_mask_cfg(d->mask_mode, d->min_active, d->base_mask_prob, d->entropy_target, d->eps, M);
+    launch_gate_fwd(d->dtype, g, s);
+    mark(ev, 2, s);
+
+    GemmNtArgs v;
+    v.a = a->x; v.w = (const char*)a->w_in + (size_t)2 * E * E * es;
+    v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
+    v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
+    v.M = M; v.H = H; v.hd = hd; v.pooled = 1;
+    launch_gemm_nt(d->dtype, v, s);
+    mark(ev, 3, s);
+
+    GemmNtArgs y;
+    y.a = o; y.w = a->w_out; y.bias = a->b_out; y.c = a->y; y.probs = nullptr; y.R = d->batch; y.N = E; y.K = E;
+    y.lda = E; y.M = 1; y.H = H; y.hd = hd; y.pooled = 0;
+    launch_gemm_nt(d->dtype, y, s);
+    mark(ev, 4, s);
+    return launch_status();
+}
+
+int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream) {
+    int st = aecf_pool_check(d);
+    if (st != AECF_OK) return st;
+    if (!a || !a->x || !a->query || !a->w_in || !a->w_out || !a->dy || !a->saved_probs || !a->saved_o || !a->dx ||
+        !a->dquery || !a->dw_in || !a->db_in || !a->dw_out || !a->db_out || !a->workspace)
+        return AECF_ERR_NULL_POINTER;
+    if (a->d_entropy && !a->attn_w) return AECF_ERR_NULL_POINTER;
+    const BwdWs L = bwd_layout(d);
+    if (a->workspace_bytes < L.total) return AECF_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)a->workspace;
+    const int E = d->embed_dim, H = d->num_heads, M = d->modalities, hd = E / H, es = esize(d->dtype);
+    const int64_t B = d->batch;
+    float* qs = (float*)(ws + L.qs);
+    float* a_f32 = (float*)(ws + L.a_f32);
+    void* wvt = ws + L.wvt;
+    void* wot = ws + L.wot;
+    void* dobuf = ws + L.dobuf;
+    float* dsbuf = (float*)(ws + L.dsbuf);
+    float* u = (float*)(ws + L.u);
+    const float scale = sqrtf(1.0f / (float)hd);
+    const char* w_v = (const char*)a->w_in + (size_t)2 * E * E * es;
+
+    void** ev = a->stage_events;
+    mark(ev, 0, s);
+    launch_prep_qs(d->dtype, a->w_in, a->b_in, a->query, qs, E, scale, s);
+    launch_prep_amat(d->dtype, a->w_in, qs, a_f32, ws + L.a_hi, ws + L.a_lo, E, H, s);
+    launch_transpose(d->dtype, w_v, wvt, E, s);
+    launch_transpose(d->dtype, a->w_out, wot, E, s);
+    mark(ev, 1, s);
+
+    // do = dy W_o   (NT GEMM against W_o^T)
+    GemmNtArgs g;
+    g.a = a->dy; g.w = wot; g.bias = nullptr; g.c = dobuf; g.probs = nullptr; g.R = B; g.N = E; g.K = E; g.lda = E;
+    g.M = 1; g.H = H; g.hd = hd; g.pooled = 0;
+    launch_gemm_nt(d->dtype, g, s);
+    mark(ev, 2, s);
+
+    // dW_o = dy^T o, db_o = colsum(dy)
+    GemmTnArgs t1;
+    t1.lhs = a->dy; t1.rhs = a->saved_o; t1.probs = nullptr; t1.dsbuf = nullptr; t1.out = (float*)(ws + L.slab_o);
+    t1.colsum = (float*)(ws + L.cs_o); t1.u = nullptr; t1.B = B; t1.M = 1; t1.E = E; t1.H = H; t1.hd = hd;
+    t1.splits = L.splits; t1.rows_per_split = L.rows_per_split; t1.pooled = 0;
+    launch_gemm_tn(d->dtype, t1, s);
+    mark(ev, 3, s);
+
+    BwdDaArgs da;
+    da.x = a->x; da.dobuf = dobuf; da.wvt = wvt; da.probs = a->saved_probs; da.d_attn_w = a->d_attn_w;
+    da.d_entropy = a->d_entropy; da.attn_w = a->attn_w; da.dsbuf = dsbuf; da.B = B; da.M = M; da.E = E; da.H = H;
+    da.hd = hd; da.log_M = (float)log((double)M);
+    launch_bwd_da(d->dtype, da, s);
+    mark(ev, 4, s);
+
+    BwdDxArgs dx;
+    dx.dobuf = dobuf; dx.wvt = wvt; dx.probs = a->saved_probs; dx.dsbuf = dsbuf; dx.a_f32 = a_f32; dx.dx = a->dx;
+    dx.B = B; dx.M = M; dx.E = E; dx.H = H; dx.hd = hd;
+    launch_bwd_dx(d->dtype, dx, s);
+    mark(ev, 5, s);
+
+    // dW_v = do^T pooled, db_v = colsum(do), u = ds^T x
+    GemmTnArgs t2;
+    t2.lhs = dobuf; t2.rhs = a->x; t2.probs = a->saved_probs; t2.dsbuf = dsbuf; t2.out = (float*)(ws + L.slab_v);
+    t2.colsum = (float*)(ws + L.cs_v); t2.u = (float*)(ws + L.u_slab); t2.B = B; t2.M = M; t2.E = E; t2.H = H;
+    t2.hd = hd; t2.splits = L.splits; t2.rows_per_split = L.rows_per_split; t2.pooled = 1;
+    launch_gemm_tn(d->dtype, t2, s);
+    mark(ev, 6, s);
+
+    launch_reduce_slabs((const float*)(ws + L.slab_o), a->dw_out, (int64_t)E * E, L.splits, s);
+    launch_reduce_slabs((const float*)(ws + L.cs_o), a->db_out, E, L.splits, s);
+    launch_reduce_slabs((const float*)(ws + L.slab_v), a->dw_in + (size_t)2 * E * E, (int64_t)E * E, L.splits, s);
+    launch_reduce_slabs((const float*)(ws + L.cs_v), a->db_in + 2 * E, E, L.splits, s);
+    launch_reduce_slabs((const float*)(ws + L.u_slab), u, (int64_t)HPAD * E, L.splits, s);
+
+    FinalizeArgs f;
+    f.w_in = a->w_in; f.query = a->query; f.qs = qs; f.u = u; f.dqp = (float*)(ws + L.dqp); f.dw_in = a->dw_in;
+    f.db_in = a->db_in; f.dquery = a->dquery; f.E = E; f.H = H; f.hd = hd; f.scale = scale;
+    launch_finalize(d->dtype, f, s);
+    mark(ev, 7, s);
+    return launch_status();
+}
+
+int aecf_curriculum_mask_forward(int64_t rows, int32_t L, int32_t mode, int32_t min_active, float base_mask_prob,
+                                 float entropy_target, float eps, const float* weights, const float* uniforms,
+                                 float* masked, float* entropy, float* mask_rate, uint8_t* mask_bits, void* stream) {
+    if (rows <= 0 || L <= 0) return AECF_ERR_BAD_DIMS;
+    if (L > 32) return AECF_ERR_UNSUPPORTED;
+    if (mode != 1 && mode != 2) return AECF_ERR_BAD_DIMS;
+    if (!weights) return AECF_ERR_NULL_POINTER;
+    if (mode == 1 && L > 1 && !uniforms) return AECF_ERR_NULL_POINTER;
+    MaskCfg c = make_mask_cfg(mode, min_active, base_mask_prob, entropy_target, eps, L);
+    launch_mask_fwd(rows, L, c, weights, uniforms, masked, entropy, mask_rate, mask_bits, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_curriculum_mask_backward(int64_t rows, int32_t L, int32_t mode, float eps, const float* weights,
+                                  const uint8_t* mask_bits, const float* d_masked, const float* d_entropy,
+                                  float* d_weights, void* stream) {
+    if (rows <= 0 || L <= 0) return AECF_ERR_BAD_DIMS;
+    if (L > 32) return AECF_ERR_UNSUPPORTED;
+    if (!weights || !d_weights) return AECF_ERR_NULL_POINTER;
+    if (mode == 1 && L > 1 && !mask_bits) return AECF_ERR_NULL_POINTER;
+    launch_mask_bwd(rows, L, mode, eps, (float)log((double)L), weights, mask_bits, d_masked, d_entropy, d_weights,
+                    (hipStream_t)stream);
+    return launch_status();
+}
+
+size_t aecf_entropy_loss_workspace_bytes(int64_t n) { (void)n; return 1024 * sizeof(float); }
+
+int aecf_entropy_loss_fwd_bwd(int64_t n, int32_t last_seq_len, float entropy_target, const float* entropy,
+                              float upstream, float* loss, float* d_entropy, void* workspace, void* stream) {
+    if (n <= 0) return AECF_ERR_BAD_DIMS;
+    if (!entropy || !loss || !workspace) return AECF_ERR_NULL_POINTER;
+    const double max_ent = last_seq_len > 1 ? log((double)last_seq_len) : 0.0;   // ref :307
+    const float target = (float)(max_ent * (double)entropy_target);
+    launch_entropy_loss(n, target, entropy, upstream, loss, d_entropy, (float*)workspace, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_sdpa_forward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype, float scale, const void* q,
+                      const void* k, const void* v, void* out, float* probs, void* stream) {
+    if (B <= 0 || S <= 0 || T <= 0 || E <= 0) return AECF_ERR_BAD_DIMS;
+    if (S > 64 || T > 64 || (dtype != AECF_BF16 && dtype != AECF_F32)) return AECF_ERR_UNSUPPORTED;
+    if (!q || !k || !v || !out) return AECF_ERR_NULL_POINTER;
+    launch_sdpa_fwd(dtype, B, S, T, E, scale, q, k, v, out, probs, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype, float scale, const void* q,
+                       const void* k, const void* v, const float* probs, const void* dout, void* dq, void* dk,
+                       void* dv, void* stream) {
+    if (B <= 0 || S <= 0 || T <= 0 || E <= 0) return AECF_ERR_BAD_DIMS;
+    if (S > 64 || T > 64 || (dtype != AECF_BF16 && dtype != AECF_F32)) return AECF_ERR_UNSUPPORTED;
+    if (!q || !k || !v || !probs || !dout || !dq || !dk || !dv) return AECF_ERR_NULL_POINTER;
+    launch_sdpa_bwd(dtype, B, S, T, E, scale, q, k, v, probs, dout, dq, dk, dv, (hipStream_t)stream);
+    return launch_status();
+}
+
+}  // extern "C"

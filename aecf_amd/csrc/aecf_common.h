@@ -1,0 +1,231 @@
+// Device-side building blocks shared by every kernel of libaecf_hip (gfx950 / CDNA4 only).
+//
+// Conventions used throughout:
+//   * one wavefront = 64 lanes; r16 = lane & 15, lg = lane >> 4.
+//   * MFMA tiles are 16x16 (v_mfma_f32_16x16x32_bf16 for bf16, v_mfma_f32_16x16x4_f32 for f32).
+//     A "fragment" is the 16 bytes one lane contributes to one K-step:
+//        bf16: 8 consecutive k (KSTEP = 32 per MFMA),  A[row r16][k0 + 8*lg + j]
+//        f32 : 4 consecutive k (KSTEP = 16 = 4 MFMAs), A[row r16][k0 + 4*lg + t] feeds MFMA t
+//     (the K order inside a step is a free choice as long as A and B agree).
+//   * accumulator (C/D) layout of a 16x16 tile: col = r16, row = 4*lg + reg   (reg = 0..3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct BF16 {};
+struct F32 {};
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned int b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;            // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return (unsigned int)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+template <typename T> struct Tr;
+
+template <> struct Tr<BF16> {
+    typedef unsigned short elem;
+    typedef u32x4 frag;                 // 8 bf16
+    static constexpr int EPL = 8;       // elements per lane per K-step
+    static constexpr int KSTEP = 32;
+    static constexpr int BYTES = 2;
+    static __device__ __forceinline__ frag zero() { return frag{0u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ frag load(const elem* p) { return *reinterpret_cast<const frag*>(p); }
+    static __device__ __forceinline__ void unpack(frag f, float* o) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(f[i] << 16);
+            o[2 * i + 1] = __uint_as_float(f[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ frag pack(const float* v) {
+        frag f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        return f;
+    }
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                       c, 0, 0, 0);
+    }
+    // 4 consecutive elements (accumulator-layout rows)
+    static __device__ __forceinline__ void load4(const elem* p, float* o) {
+        u32x2 v = *reinterpret_cast<const u32x2*>(p);
+        o[0] = __uint_as_float(v[0] << 16);
+        o[1] = __uint_as_float(v[0] & 0xffff0000u);
+        o[2] = __uint_as_float(v[1] << 16);
+        o[3] = __uint_as_float(v[1] & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store4(elem* p, const float* v) {
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(p) = o;
+    }
+    static __device__ __forceinline__ float to_f32(elem e) { return __uint_as_float(((unsigned int)e) << 16); }
+    static __device__ __forceinline__ elem from_f32(float f) { return (elem)f32_to_bf16_bits(f); }
+};
+
+template <> struct Tr<F32> {
+    typedef float elem;
+    typedef f32x4 frag;                 // 4 f32
+    static constexpr int EPL = 4;
+    static constexpr int KSTEP = 16;
+    static constexpr int BYTES = 4;
+    static __device__ __forceinline__ frag zero() { return frag{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ frag load(const elem* p) { return *reinterpret_cast<const frag*>(p); }
+    static __device__ __forceinline__ void unpack(frag f, float* o) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = f[i];
+    }
+    static __device__ __forceinline__ frag pack(const float* v) { return frag{v[0], v[1], v[2], v[3]}; }
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ void load4(const elem* p, float* o) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+    static __device__ __forceinline__ void store4(elem* p, const float* v) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    static __device__ __forceinline__ float to_f32(elem e) { return e; }
+    static __device__ __forceinline__ elem from_f32(float f) { return f; }
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// sum over the 4 lane groups (lanes l, l^16, l^32, l^48): every lane ends with the total
+__device__ __forceinline__ float reduce_lg(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// sum over the 16 lanes of one lane group
+__device__ __forceinline__ float reduce_r16(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float reduce_wave(float v) { return reduce_lg(reduce_r16(v)); }
+
+// ---------------------------------------------------------------------------------------------
+// CurriculumMasking row arithmetic (ref aecf/AECFLayer.py:130-283), one row of length L in
+// registers.  Shared by the fused gate kernel and the stand-alone mask kernel so both produce
+// bit-identical results for the same (weights, uniforms).
+// ---------------------------------------------------------------------------------------------
+struct MaskCfg {
+    int mode;             // 0 none, 1 train, 2 eval
+    int min_active;
+    float base_mask_prob;
+    float entropy_target;
+    float eps;
+    float log_L;          // (float)log((double)L), computed on the host like the reference's math.log
+    float inv_L;          // (float)(1.0 / L)
+};
+
+// x*log(x) with xlogy semantics: 0 at x==0, NaN propagates (torch.xlogy, ref :125)
+__device__ __forceinline__ float xlogx(float w) { return (w == 0.f) ? 0.f : w * logf(w); }
+
+template <int LMAX>
+__device__ __forceinline__ void curriculum_row(const MaskCfg& c, int L, float* w /*in: weights, out: normalised*/,
+                                               const float* u, float* masked, float& entropy, float& mask_rate,
+                                               unsigned int& mask_bits) {
+    const float logL = c.log_L;
+    if (c.mode == 2) {  // eval (ref :150-156): weights unchanged, entropy of the raw weights
+        float h = 0.f;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i)
+            if (i < L) { h -= xlogx(w[i]); masked[i] = w[i]; }
+        entropy = fminf(fmaxf(h, 0.f), logL);
+        if (h != h) entropy = h;
+        mask_rate = 0.f;
+        mask_bits = 0xffffffffu;
+        return;
+    }
+    if (L <= 1) {  // ref :160-167
+        masked[0] = w[0];
+        entropy = 0.f;
+        mask_rate = 0.f;
+        mask_bits = 1u;
+        return;
+    }
+    // ref :170-184  (non-finite entries -> 0; rows summing below eps -> uniform; else w / sum)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i)
+        if (i < L) {
+            if (!isfinite(w[i])) w[i] = 0.f;
+            s += w[i];
+        }
+    const bool needs_norm = s < c.eps;
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i)
+        if (i < L) w[i] = needs_norm ? c.inv_L : (w[i] / s);
+    // ref :190-201
+    float h = 0.f;
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i)
+        if (i < L) h -= xlogx(w[i]);
+    h = fminf(fmaxf(h, 0.f), logL);
+    entropy = h;
+    float ne = fminf(fmaxf(h / logL, 0.f), 1.f);
+    float keep = fminf(fmaxf(1.0f - c.base_mask_prob * ne, 0.f), 1.f);
+    // ref :204  bernoulli(keep) == (u < keep) on the float32 uniform stream
+    unsigned int bits = 0u;
+    int active = 0;
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i)
+        if (i < L && u[i] < keep) { bits |= (1u << i); ++active; }
+    // ref :207-260  min-active fix: rows with too few survivors keep exactly their top-k weights
+    const int k = c.min_active < L ? c.min_active : L;
+    if (active < k) {
+        bits = 0u;
+        for (int t = 0; t < k; ++t) {   // k selections of the largest remaining, lowest index on ties
+            int best = -1;
+            float bv = 0.f;
+#pragma unroll
+            for (int i = 0; i < LMAX; ++i)
+                if (i < L && !((bits >> i) & 1u) && (best < 0 || w[i] > bv)) { best = i; bv = w[i]; }
+            bits |= (1u << best);
+        }
+        active = k;
+    }
+    // ref :263-272
+    float ms = 0.f;
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i)
+        if (i < L) { masked[i] = ((bits >> i) & 1u) ? w[i] : 0.f; ms += masked[i]; }
+    const bool valid = ms > c.eps;
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i)
+        if (i < L) masked[i] = valid ? (masked[i] / ms) : w[i];
+    mask_rate = 1.0f - (float)active / (float)L;   // ref :275
+    mask_bits = bits;
+}
+
+#define AECF_DISPATCH_M(M, ...)                               \
+    switch (M) {                                              \
+        case 1: { constexpr int M_ = 1; __VA_ARGS__; break; } \
+        case 2: { constexpr int M_ = 2; __VA_ARGS__; break; } \
+        case 3: { constexpr int M_ = 3; __VA_ARGS__; break; } \
+        case 4: { constexpr int M_ = 4; __VA_ARGS__; break; } \
+        case 5: { constexpr int M_ = 5; __VA_ARGS__; break; } \
+        case 6: { constexpr int M_ = 6; __VA_ARGS__; break; } \
+        case 7: { constexpr int M_ = 7; __VA_ARGS__; break; } \
+        case 8: { constexpr int M_ = 8; __VA_ARGS__; break; } \
+        default: break;                                       \
+    }

@@ -1,0 +1,139 @@
+// Host-callable launchers of the device kernels (internal to libaecf_hip; the public C ABI is
+// include/aecf_hip.h).  Every launcher only enqueues work on `s`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aecf_common.h"
+
+namespace aecf {
+
+constexpr int HPAD = 16;   // heads padded to one MFMA column tile
+
+// ---------------- forward ----------------
+// qs[j] = (W_q q + b_q)[j] * scale
+void launch_prep_qs(int dtype, const void* w_in, const void* b_in, const void* query, float* qs, int E, float scale,
+                    hipStream_t s);
+// A[h][k] = sum_{j in head h} qs[j] W_k[j][k]   (f32 [HPAD][E] + dtype hi/lo copies for the MFMA B operand)
+void launch_prep_amat(int dtype, const void* w_in, const float* qs, float* a_f32, void* a_hi, void* a_lo, int E, int H,
+                      hipStream_t s);
+// dst[k][j] = src[j][k]   (E x E, dtype)
+void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t s);
+
+struct GateArgs {
+    const void* x;            // [B,M,E]
+    const void* a_hi;         // [HPAD,E] dtype
+    const void* a_lo;         // [HPAD,E] dtype (bf16 only)
+    const uint8_t* kpm;       // [B,M] or null
+    const float* uniforms;    // [B,M] or null
+    float* probs;             // [B,H,M]
+    float* attn_w;            // [B,M]
+    float* masked_w;          // [B,M] or null
+    float* entropy;           // [B] or null
+    float* mask_rate;         // [B] or null
+    int64_t B;
+    int M, E, H;
+    MaskCfg mask;
+};
+void launch_gate_fwd(int dtype, const GateArgs& a, hipStream_t s);
+
+// C[r][n] = sum_k A(r,k) W[n][k] + bias[n]
+//   pooled == 0: A(r,k) = a[r*lda + k]
+//   pooled == 1: A(r,k) = sum_m probs[r][head(n)][m] * x[r][m][k]   (a = x [R,M,K], head(n) = n / hd)
+struct GemmNtArgs {
+    const void* a;
+    const void* w;       // [N,K] dtype
+    const void* bias;    // [N] dtype or null
+    void* c;             // [R,N] dtype
+    const float* probs;  // [R,H,M] (pooled only)
+    int64_t R;
+    int N, K;
+    int64_t lda;
+    int M, H, hd;
+    int pooled;
+};
+void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
+
+// ---------------- backward ----------------
+// pass 1: da[b,h,m] = (W_v,h^T do_h[b]) . x[b,m]  ->  ds = softmax-backward  -> dsbuf [B,H,M]
+struct BwdDaArgs {
+    const void* x;        // [B,M,E]
+    const void* dobuf;    // [B,E] dtype  (dy W_o)
+    const void* wvt;      // [E(k), E(j)] dtype = W_v^T
+    const float* probs;   // [B,H,M]
+    const float* d_attn_w;   // [B,M] or null
+    const float* d_entropy;  // [B] or null (eval mode)
+    const float* attn_w;     // [B,M] (with d_entropy)
+    float* dsbuf;         // [B,H,M]
+    int64_t B;
+    int M, E, H, hd;
+    float log_M;
+};
+void launch_bwd_da(int dtype, const BwdDaArgs& a, hipStream_t s);
+
+// pass 2: dx[b,m,k] = sum_h probs[b,h,m] (W_v,h^T do_h[b])[k] + sum_h ds[b,h,m] A[h][k]
+struct BwdDxArgs {
+    const void* dobuf;
+    const void* wvt;
+    const float* probs;
+    const float* dsbuf;
+    const float* a_f32;   // [HPAD,E]
+    void* dx;             // [B,M,E] dtype
+    int64_t B;
+    int M, E, H, hd;
+};
+void launch_bwd_dx(int dtype, const BwdDxArgs& a, hipStream_t s);
+
+// out[split][j][k] = sum_{b in split} lhs[b][j] * rhs(b,k)        (f32 partial slabs, deterministic)
+//   pooled == 0: rhs(b,k) = rhs[b*E + k]
+//   pooled == 1: rhs(b,k) = sum_m probs[b][head(j)][m] x[b][m][k]
+// colsum[split][j] = sum_b lhs[b][j]
+// pooled == 1 additionally: u[split][h][k] = sum_{b,m} ds[b,h,m] x[b,m,k]
+struct GemmTnArgs {
+    const void* lhs;      // [B,E] dtype
+    const void* rhs;      // [B,E] dtype or x [B,M,E]
+    const float* probs;   // pooled
+    const float* dsbuf;   // pooled
+    float* out;           // [S,E,E]
+    float* colsum;        // [S,E]
+    float* u;             // [S,HPAD,E] pooled
+    int64_t B;
+    int M, E, H, hd;
+    int splits;           // S
+    int64_t rows_per_split;   // multiple of 32
+    int pooled;
+};
+void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
+
+// dst[i] = sum_s src[s][i]    (n elements, S slabs)
+void launch_reduce_slabs(const float* src, float* dst, int64_t n, int S, hipStream_t s);
+
+// dW_k[j][k] = qs[j] u[h(j)][k];  dqp[j] = scale * sum_k W_k[j][k] u[h(j)][k]
+// dW_q[j][k] = dqp[j] q[k]; db_q = dqp; db_k = 0; dquery[k] = sum_j dqp[j] W_q[j][k]
+struct FinalizeArgs {
+    const void* w_in;
+    const void* query;
+    const float* qs;
+    const float* u;       // [HPAD,E] reduced
+    float* dqp;           // [E] scratch
+    float* dw_in;         // [3E,E]
+    float* db_in;         // [3E]
+    float* dquery;        // [E]
+    int E, H, hd;
+    float scale;
+};
+void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s);
+
+// ---------------- stand-alone pieces ----------------
+void launch_mask_fwd(int64_t rows, int L, const MaskCfg& cfg, const float* w, const float* u, float* masked,
+                     float* entropy, float* mask_rate, uint8_t* bits, hipStream_t s);
+void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, const float* w, const uint8_t* bits,
+                     const float* d_masked, const float* d_entropy, float* d_w, hipStream_t s);
+void launch_entropy_loss(int64_t n, float target, const float* entropy, float upstream, float* loss, float* d_entropy,
+                         float* partial, hipStream_t s);
+void launch_sdpa_fwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,
+                     void* out, float* probs, hipStream_t s);
+void launch_sdpa_bwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,
+                     const float* probs, const void* dout, void* dq, void* dk, void* dv, hipStream_t s);
+
+}  // namespace aecf

@@ -1,0 +1,281 @@
+// Stand-alone pieces of the AECF surface: CurriculumMasking forward/backward on free-standing weight
+// rows, entropy_loss forward+backward, projection-free single-head attention.  gfx950.
+#include "aecf_kernels.h"
+
+namespace aecf {
+
+// ------------------------------------------------------------------------------------------
+// CurriculumMasking.forward (ref aecf/AECFLayer.py:130-283): one thread per row
+template <int LMAX>
+__global__ __launch_bounds__(256) void mask_fwd_kernel(int64_t rows, int L, MaskCfg cfg, const float* __restrict__ w,
+                                                       const float* __restrict__ u, float* __restrict__ masked,
+                                                       float* __restrict__ entropy, float* __restrict__ mask_rate,
+                                                       uint8_t* __restrict__ bits_out) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float wv[LMAX], uv[LMAX], mk[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) {
+        wv[i] = i < L ? w[row * L + i] : 0.f;
+        uv[i] = (i < L && u) ? u[row * L + i] : 0.f;
+        mk[i] = 0.f;
+    }
+    float ent, rate;
+    unsigned int bits;
+    curriculum_row<LMAX>(cfg, L, wv, uv, mk, ent, rate, bits);
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i)
+        if (i < L) {
+            if (masked) masked[row * L + i] = mk[i];
+            if (bits_out) bits_out[row * L + i] = (uint8_t)((bits >> i) & 1u);
+        }
+    if (entropy) entropy[row] = ent;
+    if (mask_rate) mask_rate[row] = rate;
+}
+
+// gradient of the stand-alone module's outputs w.r.t. its input weights.
+// train: final = valid ? (w_n * mask) / sum(w_n * mask) : w_n, w_n = w / sum(w)   (entropy detached, ref :278)
+// eval : masked = w (identity), entropy = clamp(-sum xlogy(w,w))
+template <int LMAX>
+__global__ __launch_bounds__(256) void mask_bwd_kernel(int64_t rows, int L, int mode, float eps, float log_L,
+                                                       const float* __restrict__ w, const uint8_t* __restrict__ bits,
+                                                       const float* __restrict__ d_masked,
+                                                       const float* __restrict__ d_entropy, float* __restrict__ d_w) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float wv[LMAX], g[LMAX], out[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) {
+        wv[i] = i < L ? w[row * L + i] : 0.f;
+        g[i] = (i < L && d_masked) ? d_masked[row * L + i] : 0.f;
+        out[i] = 0.f;
+    }
+    if (mode == 2) {
+        float h = 0.f;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i)
+            if (i < L) h -= xlogx(wv[i]);
+        const bool live = (h >= 0.f) && (h <= log_L);
+        const float de = d_entropy ? d_entropy[row] : 0.f;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i)
+            if (i < L) out[i] = g[i] + ((live && d_entropy) ? -(logf(wv[i]) + 1.0f) * de : 0.f);
+    } else if (L <= 1) {
+        out[0] = g[0];
+    } else {
+        bool fin[LMAX];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) {
+            fin[i] = isfinite(wv[i]);
+            if (!fin[i]) wv[i] = 0.f;
+            if (i < L) s += wv[i];
+        }
+        if (!(s < eps)) {
+            float wn[LMAX], mk[LMAX];
+            float ms = 0.f;
+#pragma unroll
+            for (int i = 0; i < LMAX; ++i) {
+                wn[i] = wv[i] / s;
+                mk[i] = (i < L && bits[row * L + i]) ? 1.f : 0.f;
+                ms += wn[i] * mk[i];
+            }
+            float dwn[LMAX];
+            if (ms > eps) {
+                float dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < LMAX; ++i) dot += g[i] * (wn[i] * mk[i] / ms);
+#pragma unroll
+                for (int i = 0; i < LMAX; ++i) dwn[i] = mk[i] * (g[i] - dot) / ms;
+            } else {
+#pragma unroll
+                for (int i = 0; i < LMAX; ++i) dwn[i] = g[i];
+            }
+            float dot2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < LMAX; ++i) dot2 += dwn[i] * wn[i];
+#pragma unroll
+            for (int i = 0; i < LMAX; ++i) out[i] = fin[i] ? (dwn[i] - dot2) / s : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i)
+        if (i < L) d_w[row * L + i] = out[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// entropy_loss (ref aecf/AECFLayer.py:285-314): mean((nan_to_num(H) - target)^2), two-stage reduce
+__device__ __forceinline__ float nan_to_num_ref(float e) {   // nan=0, +inf=1, -inf=0 (ref :296)
+    if (e != e) return 0.f;
+    if (isinf(e)) return e > 0.f ? 1.f : 0.f;
+    return e;
+}
+
+__global__ __launch_bounds__(256) void entropy_loss_partial_kernel(int64_t n, float target, const float* __restrict__ e,
+                                                                   float scale_grad, float* __restrict__ d_e,
+                                                                   float* __restrict__ partial) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float raw = e[i];
+        const float d = nan_to_num_ref(raw) - target;
+        acc += d * d;
+        if (d_e) d_e[i] = isfinite(raw) ? scale_grad * d : 0.f;
+    }
+    acc = reduce_wave(acc);
+    if (lane_id() == 0) red[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void entropy_loss_final_kernel(int nblk, float inv_n, const float* __restrict__ partial,
+                                                                 float* __restrict__ loss) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
+    acc = reduce_wave(acc);
+    if (lane_id() == 0) red[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = fmaxf((red[0] + red[1] + red[2] + red[3]) * inv_n, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------
+// projection-free attention (ref aecf/AECFLayer.py:556-581).  One block per batch element; S, T <= 64.
+template <typename T>
+__global__ __launch_bounds__(256) void sdpa_fwd_kernel(int S, int Tn, int E, float scale,
+                                                       const typename Tr<T>::elem* __restrict__ q,
+                                                       const typename Tr<T>::elem* __restrict__ k,
+                                                       const typename Tr<T>::elem* __restrict__ v,
+                                                       typename Tr<T>::elem* __restrict__ out, float* __restrict__ probs) {
+    using X = Tr<T>;
+    __shared__ float sc[64][65];
+    const int64_t b = blockIdx.x;
+    const int lane = lane_id(), w = wave_id();
+    q += b * S * (int64_t)E; k += b * Tn * (int64_t)E; v += b * Tn * (int64_t)E; out += b * S * (int64_t)E;
+    for (int pair = w; pair < S * Tn; pair += 4) {
+        const int s = pair / Tn, t = pair % Tn;
+        float a = 0.f;
+        for (int e = lane; e < E; e += 64) a += X::to_f32(q[(int64_t)s * E + e]) * X::to_f32(k[(int64_t)t * E + e]);
+        a = reduce_wave(a);
+        if (lane == 0) sc[s][t] = a * scale;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += 256) {
+        float mx = -INFINITY;
+        for (int t = 0; t < Tn; ++t) mx = fmaxf(mx, sc[s][t]);
+        float sum = 0.f;
+        for (int t = 0; t < Tn; ++t) { float ex = expf(sc[s][t] - mx); sc[s][t] = ex; sum += ex; }
+        for (int t = 0; t < Tn; ++t) { float pv = sc[s][t] / sum; sc[s][t] = pv; if (probs) probs[(b * S + s) * Tn + t] = pv; }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < S * E; idx += 256) {
+        const int s = idx / E, e = idx % E;
+        float a = 0.f;
+        for (int t = 0; t < Tn; ++t) a += sc[s][t] * X::to_f32(v[(int64_t)t * E + e]);
+        out[idx] = X::from_f32(a);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sdpa_bwd_kernel(int S, int Tn, int E, float scale,
+                                                       const typename Tr<T>::elem* __restrict__ q,
+                                                       const typename Tr<T>::elem* __restrict__ k,
+                                                       const typename Tr<T>::elem* __restrict__ v,
+                                                       const float* __restrict__ probs,
+                                                       const typename Tr<T>::elem* __restrict__ dout,
+                                                       typename Tr<T>::elem* __restrict__ dq,
+                                                       typename Tr<T>::elem* __restrict__ dk,
+                                                       typename Tr<T>::elem* __restrict__ dv) {
+    using X = Tr<T>;
+    __shared__ float pp[64][65];
+    __shared__ float ds[64][65];
+    const int64_t b = blockIdx.x;
+    const int lane = lane_id(), w = wave_id();
+    q += b * S * (int64_t)E; k += b * Tn * (int64_t)E; v += b * Tn * (int64_t)E; dout += b * S * (int64_t)E;
+    dq += b * S * (int64_t)E; dk += b * Tn * (int64_t)E; dv += b * Tn * (int64_t)E;
+    for (int pair = w; pair < S * Tn; pair += 4) {
+        const int s = pair / Tn, t = pair % Tn;
+        float a = 0.f;
+        for (int e = lane; e < E; e += 64) a += X::to_f32(dout[(int64_t)s * E + e]) * X::to_f32(v[(int64_t)t * E + e]);
+        a = reduce_wave(a);
+        if (lane == 0) { ds[s][t] = a; pp[s][t] = probs[(b * S + s) * Tn + t]; }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += 256) {
+        float dot = 0.f;
+        for (int t = 0; t < Tn; ++t) dot += pp[s][t] * ds[s][t];
+        for (int t = 0; t < Tn; ++t) ds[s][t] = pp[s][t] * (ds[s][t] - dot) * scale;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < S * E; idx += 256) {
+        const int s = idx / E, e = idx % E;
+        float a = 0.f;
+        for (int t = 0; t < Tn; ++t) a += ds[s][t] * X::to_f32(k[(int64_t)t * E + e]);
+        dq[idx] = X::from_f32(a);
+    }
+    for (int idx = threadIdx.x; idx < Tn * E; idx += 256) {
+        const int t = idx / E, e = idx % E;
+        float a = 0.f, c = 0.f;
+        for (int s = 0; s < S; ++s) {
+            a += ds[s][t] * X::to_f32(q[(int64_t)s * E + e]);
+            c += pp[s][t] * X::to_f32(dout[(int64_t)s * E + e]);
+        }
+        dk[idx] = X::from_f32(a);
+        dv[idx] = X::from_f32(c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+void launch_mask_fwd(int64_t rows, int L, const MaskCfg& cfg, const float* w, const float* u, float* masked,
+                     float* entropy, float* mask_rate, uint8_t* bits, hipStream_t s) {
+    dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+    if (L <= 4) mask_fwd_kernel<4><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
+    else if (L <= 8) mask_fwd_kernel<8><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
+    else if (L <= 16) mask_fwd_kernel<16><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
+    else mask_fwd_kernel<32><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
+}
+
+void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, const float* w, const uint8_t* bits,
+                     const float* d_masked, const float* d_entropy, float* d_w, hipStream_t s) {
+    dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+    if (L <= 4) mask_bwd_kernel<4><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
+    else if (L <= 8) mask_bwd_kernel<8><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
+    else if (L <= 16) mask_bwd_kernel<16><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
+    else mask_bwd_kernel<32><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
+}
+
+void launch_entropy_loss(int64_t n, float target, const float* entropy, float upstream, float* loss, float* d_entropy,
+                         float* partial, hipStream_t s) {
+    int nblk = (int)((n + 255) / 256);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    const float inv_n = 1.0f / (float)n;
+    entropy_loss_partial_kernel<<<dim3(nblk), dim3(256), 0, s>>>(n, target, entropy, 2.0f * inv_n * upstream, d_entropy,
+                                                                partial);
+    entropy_loss_final_kernel<<<dim3(1), dim3(256), 0, s>>>(nblk, inv_n, partial, loss);
+}
+
+void launch_sdpa_fwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,
+                     void* out, float* probs, hipStream_t s) {
+    dim3 grid((unsigned)B), block(256);
+    if (dtype == 0)
+        sdpa_fwd_kernel<BF16><<<grid, block, 0, s>>>(S, T, E, scale, (const unsigned short*)q, (const unsigned short*)k,
+                                                     (const unsigned short*)v, (unsigned short*)out, probs);
+    else
+        sdpa_fwd_kernel<F32><<<grid, block, 0, s>>>(S, T, E, scale, (const float*)q, (const float*)k, (const float*)v,
+                                                    (float*)out, probs);
+}
+
+void launch_sdpa_bwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,
+                     const float* probs, const void* dout, void* dq, void* dk, void* dv, hipStream_t s) {
+    dim3 grid((unsigned)B), block(256);
+    if (dtype == 0)
+        sdpa_bwd_kernel<BF16><<<grid, block, 0, s>>>(S, T, E, scale, (const unsigned short*)q, (const unsigned short*)k,
+                                                     (const unsigned short*)v, probs, (const unsigned short*)dout,
+                                                     (unsigned short*)dq, (unsigned short*)dk, (unsigned short*)dv);
+    else
+        sdpa_bwd_kernel<F32><<<grid, block, 0, s>>>(S, T, E, scale, (const float*)q, (const float*)k, (const float*)v, probs,
+                                                    (const float*)dout, (float*)dq, (float*)dk, (float*)dv);
+}
+
+}  // namespace aecf

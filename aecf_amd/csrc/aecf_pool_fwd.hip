@@ -1,0 +1,334 @@
+// Forward kernels of the AECF fusion pool (shared-query hot path), gfx950.
+//
+// Algebra (exact re-association of torch multi_head_attention_forward, functional.py:6576-6612,
+// for ONE query shared by the whole batch -- ref aecf/AECFLayer.py:694-695):
+//   qs      = (W_q q + b_q) / sqrt(hd)                                   [E]        prep_qs
+//   A[h]    = W_k,h^T qs_h                                               [H,E]      prep_amat
+//   s[b,h,m]= x[b,m,:] . A[h]   (+ b_k,h.qs_h, constant over m: cancels in the softmax)
+//   a       = softmax_m(s);  wbar[b,m] = mean_h a[b,h,m]                            gate_fwd (MFMA)
+//   o[b,hj] = W_v,h (sum_m a[b,h,m] x[b,m,:]) + b_v                                 gemm_nt (pooled A operand, MFMA)
+//   y       = o W_o^T + b_o                                                         gemm_nt
+// The K projection never materialises; the V projection runs once per sample instead of once per
+// (sample, modality).
+#include "aecf_kernels.h"
+
+namespace aecf {
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void prep_qs_kernel(const typename Tr<T>::elem* __restrict__ w_in,
+                                                      const typename Tr<T>::elem* __restrict__ b_in,
+                                                      const typename Tr<T>::elem* __restrict__ q, float* __restrict__ qs,
+                                                      int E, float scale) {
+    using X = Tr<T>;
+    const int j = blockIdx.x * 4 + wave_id();
+    if (j >= E) return;
+    const int lane = lane_id();
+    float acc = 0.f;
+    for (int k = lane; k < E; k += 64) acc += X::to_f32(w_in[(int64_t)j * E + k]) * X::to_f32(q[k]);
+    acc = reduce_wave(acc);
+    if (lane == 0) qs[j] = (acc + (b_in ? X::to_f32(b_in[j]) : 0.f)) * scale;
+}
+
+// grid (E/64, HPAD); block 256 = 4 j-groups x 64 k
+template <typename T>
+__global__ __launch_bounds__(256) void prep_amat_kernel(const typename Tr<T>::elem* __restrict__ w_in,
+                                                        const float* __restrict__ qs, float* __restrict__ a_f32,
+                                                        typename Tr<T>::elem* __restrict__ a_hi,
+                                                        typename Tr<T>::elem* __restrict__ a_lo, int E, int H) {
+    using X = Tr<T>;
+    __shared__ float red[4][64];
+    const int h = blockIdx.y;
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int jg = threadIdx.x >> 6;
+    const int hd = E / H;
+    float acc = 0.f;
+    if (h < H) {
+        const typename X::elem* wk = w_in + (int64_t)E * E;   // W_k block of the packed in_proj_weight
+        for (int j = jg; j < hd; j += 4) acc += qs[h * hd + j] * X::to_f32(wk[(int64_t)(h * hd + j) * E + k]);
+    }
+    red[jg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (jg == 0) {
+        const int t = threadIdx.x;
+        float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        a_f32[h * E + k] = v;
+        typename X::elem hi = X::from_f32(v);
+        a_hi[h * E + k] = hi;
+        if (a_lo) a_lo[h * E + k] = X::from_f32(v - X::to_f32(hi));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const typename Tr<T>::elem* __restrict__ src,
+                                                        typename Tr<T>::elem* __restrict__ dst, int E) {
+    __shared__ typename Tr<T>::elem tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(int64_t)(j0 + r) * E + k0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) dst[(int64_t)(k0 + r) * E + j0 + tx] = tile[tx][r];
+}
+
+// ------------------------------------------------------------------------------------------
+// gate_fwd: scores via MFMA (x rows as the A operand, A^T as the B operand), softmax over the M
+// modalities in registers, head mean by a 16-lane butterfly, curriculum masking per sample.
+// One wave = 16 samples; a block = 4 waves.
+template <typename T, int M_>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(GateArgs p) {
+    using X = Tr<T>;
+    typedef typename X::elem elem;
+    typedef typename X::frag frag;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave_id()) * 16;
+    if (b0 >= p.B) return;
+    const int E = p.E, H = p.H;
+    const int64_t brow = (b0 + r16 < p.B) ? (b0 + r16) : (p.B - 1);
+    const elem* xrow = reinterpret_cast<const elem*>(p.x) + brow * M_ * (int64_t)E + X::EPL * lg;
+    const elem* ahi = reinterpret_cast<const elem*>(p.a_hi) + (int64_t)r16 * E + X::EPL * lg;
+    const elem* alo = reinterpret_cast<const elem*>(p.a_lo) + (int64_t)r16 * E + X::EPL * lg;
+
+    f32x4 acc[M_];
+#pragma unroll
+    for (int m = 0; m < M_; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < E; k0 += X::KSTEP) {
+        frag bh = X::load(ahi + k0);
+        frag bl;
+        if (X::BYTES == 2) bl = X::load(alo + k0);
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            frag xf = X::load(xrow + (int64_t)m * E + k0);
+            acc[m] = X::mma(xf, bh, acc[m]);
+            if (X::BYTES == 2) acc[m] = X::mma(xf, bl, acc[m]);
+        }
+    }
+
+    // acc[m][r]: sample b0 + 4*lg + r, head r16
+    float pr[M_][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t bs = b0 + 4 * lg + r;
+        const int64_t bc = bs < p.B ? bs : p.B - 1;
+        float sc[M_];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            sc[m] = acc[m][r];
+            if (p.kpm && p.kpm[bc * M_ + m]) sc[m] = -INFINITY;
+            mx = fmaxf(mx, sc[m]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < M_; ++m) { sc[m] = expf(sc[m] - mx); sum += sc[m]; }
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            pr[m][r] = sc[m] / sum;
+            if (r16 < H && bs < p.B) p.probs[(bs * H + r16) * M_ + m] = pr[m][r];
+        }
+    }
+    // head mean: zero the padded head columns, butterfly over the 16 lanes of the group
+    const float invH = 1.0f / (float)H;
+    float wsel[M_];
+#pragma unroll
+    for (int m = 0; m < M_; ++m) {
+        wsel[m] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = reduce_r16(r16 < H ? pr[m][r] : 0.f) * invH;
+            if (r16 == r) wsel[m] = v;
+        }
+    }
+    if (r16 < 4) {
+        const int64_t bs = b0 + 4 * lg + r16;
+        if (bs < p.B) {
+#pragma unroll
+            for (int m = 0; m < M_; ++m) p.attn_w[bs * M_ + m] = wsel[m];
+            if (p.mask.mode != 0) {
+                float w[M_], u[M_], mk[M_];
+#pragma unroll
+                for (int m = 0; m < M_; ++m) {
+                    w[m] = wsel[m];
+                    u[m] = (p.mask.mode == 1 && p.uniforms) ? p.uniforms[bs * M_ + m] : 0.f;
+                }
+                float ent, rate;
+                unsigned int bits;
+                curriculum_row<M_>(p.mask, M_, w, u, mk, ent, rate, bits);
+                if (p.masked_w) {
+#pragma unroll
+                    for (int m = 0; m < M_; ++m) p.masked_w[bs * M_ + m] = mk[m];
+                }
+                if (p.entropy) p.entropy[bs] = ent;
+                if (p.mask_rate) p.mask_rate[bs] = rate;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt: C[R,N] = A(R,K) W[N,K]^T + bias.  Block = 4 waves; block tile 64 rows x 256 cols; each wave
+// owns 64 x 64 (4 x 4 MFMA tiles, 64 accumulator registers).  Operand fragments are loaded straight
+// from global memory (weights are L2-resident; x/o stream once per column block).
+// POOLED: the A fragment of column tile ct is the probability-weighted sum over modalities of the x
+// fragments, formed in registers (fp32 FMA, rounded once to the MFMA input type).
+template <typename T, int M_, bool POOLED>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
+    using X = Tr<T>;
+    typedef typename X::elem elem;
+    typedef typename X::frag frag;
+    constexpr int RT = 4, CT = 4;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 256 + wave_id() * 64;
+    if (n0 >= p.N) return;
+    const int nct = (p.N - n0) >= 64 ? CT : (p.N - n0) / 16;
+    const int K = p.K;
+
+    const elem* wbase = reinterpret_cast<const elem*>(p.w) + (int64_t)(n0 + r16) * K + X::EPL * lg;
+    const elem* abase[RT];
+    int64_t rowc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        int64_t row = r0 + 16 * rt + r16;
+        rowc[rt] = row < p.R ? row : p.R - 1;
+        abase[rt] = reinterpret_cast<const elem*>(p.a) + rowc[rt] * p.lda + X::EPL * lg;
+    }
+    // probabilities for the pooled operand: pr[rt][ct][m] = probs[row][head(ct)][m]
+    float pr[RT][CT][M_];
+    int head[CT];
+    if (POOLED) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            int h = (n0 + 16 * ct) / p.hd;
+            head[ct] = h < p.H ? h : p.H - 1;
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int m = 0; m < M_; ++m) pr[rt][ct][m] = p.probs[(rowc[rt] * p.H + head[ct]) * M_ + m];
+    }
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < K; k0 += X::KSTEP) {
+        frag wf[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            wf[ct] = (ct < nct) ? X::load(wbase + (int64_t)(16 * ct) * K + k0) : X::zero();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (!POOLED) {
+                frag af = X::load(abase[rt] + k0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    if (ct < nct) acc[rt][ct] = X::mma(af, wf[ct], acc[rt][ct]);
+            } else {
+                float xm[M_][X::EPL];
+#pragma unroll
+                for (int m = 0; m < M_; ++m) X::unpack(X::load(abase[rt] + (int64_t)m * K + k0), xm[m]);
+                frag pa = X::zero();
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (ct < nct) {
+                        if (ct == 0 || head[ct] != head[ct - 1]) {
+                            float pv[X::EPL];
+#pragma unroll
+                            for (int j = 0; j < X::EPL; ++j) {
+                                float v = pr[rt][ct][0] * xm[0][j];
+#pragma unroll
+                                for (int m = 1; m < M_; ++m) v = fmaf(pr[rt][ct][m], xm[m][j], v);
+                                pv[j] = v;
+                            }
+                            pa = X::pack(pv);
+                        }
+                        acc[rt][ct] = X::mma(pa, wf[ct], acc[rt][ct]);
+                    }
+                }
+            }
+        }
+    }
+
+    elem* c = reinterpret_cast<elem*>(p.c);
+    const elem* bias = reinterpret_cast<const elem*>(p.bias);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        if (ct < nct) {
+            const int n = n0 + 16 * ct + r16;
+            const float bv = bias ? X::to_f32(bias[n]) : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = r0 + 16 * rt + 4 * lg + r;
+                    if (row < p.R) c[row * p.N + n] = X::from_f32(acc[rt][ct][r] + bv);
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+#define LAUNCH_CHECKED(...) __VA_ARGS__
+
+void launch_prep_qs(int dtype, const void* w_in, const void* b_in, const void* query, float* qs, int E, float scale,
+                    hipStream_t s) {
+    dim3 grid((E + 3) / 4), block(256);
+    if (dtype == 0)
+        prep_qs_kernel<BF16><<<grid, block, 0, s>>>((const unsigned short*)w_in, (const unsigned short*)b_in,
+                                                    (const unsigned short*)query, qs, E, scale);
+    else
+        prep_qs_kernel<F32><<<grid, block, 0, s>>>((const float*)w_in, (const float*)b_in, (const float*)query, qs, E,
+                                                   scale);
+}
+
+void launch_prep_amat(int dtype, const void* w_in, const float* qs, float* a_f32, void* a_hi, void* a_lo, int E, int H,
+                      hipStream_t s) {
+    dim3 grid(E / 64, HPAD), block(256);
+    if (dtype == 0)
+        prep_amat_kernel<BF16><<<grid, block, 0, s>>>((const unsigned short*)w_in, qs, a_f32, (unsigned short*)a_hi,
+                                                      (unsigned short*)a_lo, E, H);
+    else
+        prep_amat_kernel<F32><<<grid, block, 0, s>>>((const float*)w_in, qs, a_f32, (float*)a_hi, (float*)nullptr, E, H);
+}
+
+void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t s) {
+    dim3 grid(E / 32, E / 32), block(256);
+    if (dtype == 0)
+        transpose_kernel<BF16><<<grid, block, 0, s>>>((const unsigned short*)src, (unsigned short*)dst, E);
+    else
+        transpose_kernel<F32><<<grid, block, 0, s>>>((const float*)src, (float*)dst, E);
+}
+
+void launch_gate_fwd(int dtype, const GateArgs& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.B + 63) / 64)), block(256);
+    AECF_DISPATCH_M(a.M, {
+        if (dtype == 0)
+            gate_fwd_kernel<BF16, M_><<<grid, block, 0, s>>>(a);
+        else
+            gate_fwd_kernel<F32, M_><<<grid, block, 0, s>>>(a);
+    });
+}
+
+void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.R + 63) / 64), (a.N + 255) / 256), block(256);
+    if (!a.pooled) {
+        if (dtype == 0)
+            gemm_nt_kernel<BF16, 1, false><<<grid, block, 0, s>>>(a);
+        else
+            gemm_nt_kernel<F32, 1, false><<<grid, block, 0, s>>>(a);
+        return;
+    }
+    AECF_DISPATCH_M(a.M, {
+        if (dtype == 0)
+            gemm_nt_kernel<BF16, M_, true><<<grid, block, 0, s>>>(a);
+        else
+            gemm_nt_kernel<F32, M_, true><<<grid, block, 0, s>>>(a);
+    });
+}
+
+}  // namespace aecf

@@ -1,0 +1,543 @@
+"""Host-side mirror of the reference's operator interface for the fusion path.
+
+Same names, signatures, validation messages, ``info`` dictionary and state_dict keys as
+``aecf/AECFLayer.py`` of leochlon/aecf (cited as ``ref:`` below); the arithmetic is done by
+hand-written HIP kernels in ``libaecf_hip.so`` reached through ctypes (``_lib.py``).  PyTorch is
+used for device memory, streams, autograd bookkeeping and parameter storage only.
+
+There is no CPU path and no PyTorch fallback: tensors must live on a ROCm device and the library
+must be present, otherwise a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+__all__ = ['CurriculumMasking', 'MultimodalAttentionPool', 'multimodal_attention_pool', 'create_fusion_pool']
+
+_DTYPES = {torch.bfloat16: _lib.AECF_BF16, torch.float32: _lib.AECF_F32}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# Test hook: parity tests need the mask drawn from the SAME uniforms the CPU oracle consumed.  When set
+# to a tensor, the next forward uses it instead of torch.rand (and clears it).  Never set in production.
+_uniforms_override: Optional[torch.Tensor] = None
+
+
+def _draw_uniforms(shape, device) -> torch.Tensor:
+    global _uniforms_override
+    if _uniforms_override is not None:
+        u = _uniforms_override.to(device=device, dtype=torch.float32).reshape(shape).contiguous()
+        _uniforms_override = None
+        return u
+    return torch.rand(shape, dtype=torch.float32, device=device)
+
+
+def _require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"aecf_amd: {what} must be on a ROCm device (got {t.device}); this package has no CPU path")
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd bridges (one per C-ABI operator)
+# ----------------------------------------------------------------------------------------------
+class _PoolFunction(torch.autograd.Function):
+    """aecf_pool_forward / aecf_pool_backward.  Outputs: y [B,E], attn_w [B,M] f32, masked_w [B,M],
+    entropy [B], mask_rate [B] (all f32)."""
+
+    @staticmethod
+    def forward(ctx, x, q, w_in, b_in, w_out, b_out, kpm, uniforms, num_heads, mask_mode, min_active,
+                base_mask_prob, entropy_target, eps):
+        lib = _lib.load()
+        B, M, E = x.shape
+        dt = x.dtype
+        desc = _lib.PoolDesc(B, M, E, num_heads, _DTYPES[dt], mask_mode, min_active, base_mask_prob,
+                             entropy_target, eps)
+        _lib.check(lib.aecf_pool_check(ctypes.byref(desc)), "aecf_pool_check")
+        xc = x.contiguous()
+        qc = q.detach().reshape(E).to(dt).contiguous()
+        w_in_c = w_in.detach().to(dt).contiguous()
+        w_out_c = w_out.detach().to(dt).contiguous()
+        b_in_c = None if b_in is None else b_in.detach().to(dt).contiguous()
+        b_out_c = None if b_out is None else b_out.detach().to(dt).contiguous()
+        dev = x.device
+        y = torch.empty(B, E, dtype=dt, device=dev)
+        attn_w = torch.empty(B, M, dtype=torch.float32, device=dev)
+        probs = torch.empty(B, num_heads, M, dtype=torch.float32, device=dev)
+        saved_o = torch.empty(B, E, dtype=dt, device=dev)
+        if mask_mode != 0:
+            masked_w = torch.empty(B, M, dtype=torch.float32, device=dev)
+            entropy = torch.empty(B, dtype=torch.float32, device=dev)
+            mask_rate = torch.empty(B, dtype=torch.float32, device=dev)
+        else:
+            masked_w = entropy = mask_rate = None
+        ws_bytes = lib.aecf_pool_fwd_workspace_bytes(ctypes.byref(desc))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        args = _lib.PoolFwdArgs(
+            _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(b_out_c), _ptr(kpm),
+            _ptr(uniforms), _ptr(y), _ptr(attn_w), _ptr(masked_w), _ptr(entropy), _ptr(mask_rate),
+            _ptr(probs), _ptr(saved_o), _ptr(ws), ws_bytes,
+            None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd))
+        _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
+        ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w)
+        ctx.desc = desc
+        ctx.q_shape = q.shape
+        ctx.param_dtypes = (q.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
+                            None if b_out is None else b_out.dtype)
+        ctx.has_bias = (b_in is not None, b_out is not None)
+        outs = (y, attn_w, masked_w, entropy, mask_rate)
+        nondiff = [t for t in (masked_w, mask_rate) if t is not None]
+        if entropy is not None and mask_mode == 1:
+            nondiff.append(entropy)            # train mode: entropy is detached (ref :278)
+        ctx.mark_non_differentiable(*nondiff)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dy, d_attn_w, _d_masked, d_entropy, _d_rate):
+        lib = _lib.load()
+        xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w = ctx.saved_tensors
+        desc = ctx.desc
+        B, M, E = xc.shape
+        dev = xc.device
+        dt = xc.dtype
+        dy_c = torch.zeros(B, E, dtype=dt, device=dev) if dy is None else dy.to(dt).contiguous()
+        daw = None if d_attn_w is None else d_attn_w.to(torch.float32).contiguous()
+        dent = None
+        if d_entropy is not None and desc.mask_mode == 2:
+            dent = d_entropy.to(torch.float32).contiguous()
+        dx = torch.empty_like(xc)
+        dquery = torch.empty(E, dtype=torch.float32, device=dev)
+        dw_in = torch.empty(3 * E, E, dtype=torch.float32, device=dev)
+        db_in = torch.empty(3 * E, dtype=torch.float32, device=dev)
+        dw_out = torch.empty(E, E, dtype=torch.float32, device=dev)
+        db_out = torch.empty(E, dtype=torch.float32, device=dev)
+        ws_bytes = lib.aecf_pool_bwd_workspace_bytes(ctypes.byref(desc))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        args = _lib.PoolBwdArgs(
+            _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(dy_c), _ptr(daw), _ptr(dent),
+            _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
+            _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes,
+            None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd))
+        _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")
+        qd, wid, bid, wod, bod = ctx.param_dtypes
+        needs = ctx.needs_input_grad
+        return (dx if needs[0] else None,
+                dquery.to(qd).reshape(ctx.q_shape) if needs[1] else None,
+                dw_in.to(wid) if needs[2] else None,
+                db_in.to(bid) if (ctx.has_bias[0] and needs[3]) else None,
+                dw_out.to(wod) if needs[4] else None,
+                db_out.to(bod) if (ctx.has_bias[1] and needs[5]) else None,
+                None, None, None, None, None, None, None, None)
+
+
+class _MaskFunction(torch.autograd.Function):
+    """aecf_curriculum_mask_forward / _backward on free-standing weight rows."""
+
+    @staticmethod
+    def forward(ctx, weights, uniforms, mode, min_active, base_mask_prob, entropy_target, eps):
+        lib = _lib.load()
+        L = weights.shape[-1]
+        rows = weights.numel() // L
+        w32 = weights.detach().to(torch.float32).contiguous()
+        dev = weights.device
+        masked = torch.empty_like(w32)
+        entropy = torch.empty(weights.shape[:-1], dtype=torch.float32, device=dev)
+        mask_rate = torch.empty(weights.shape[:-1], dtype=torch.float32, device=dev)
+        bits = torch.empty(weights.shape, dtype=torch.uint8, device=dev)
+        _lib.check(lib.aecf_curriculum_mask_forward(
+            rows, L, mode, min_active, base_mask_prob, entropy_target, eps, _ptr(w32), _ptr(uniforms), _ptr(masked),
+            _ptr(entropy), _ptr(mask_rate), _ptr(bits), _stream()), "aecf_curriculum_mask_forward")
+        ctx.save_for_backward(w32, bits)
+        ctx.cfg = (rows, L, mode, eps, weights.dtype)
+        if mode == 1:
+            ctx.mark_non_differentiable(entropy, mask_rate)
+        else:
+            ctx.mark_non_differentiable(mask_rate)
+        return masked, entropy, mask_rate
+
+    @staticmethod
+    def backward(ctx, d_masked, d_entropy, _d_rate):
+        lib = _lib.load()
+        w32, bits = ctx.saved_tensors
+        rows, L, mode, eps, wdt = ctx.cfg
+        dm = None if d_masked is None else d_masked.to(torch.float32).contiguous()
+        de = None if (d_entropy is None or mode != 2) else d_entropy.to(torch.float32).contiguous()
+        dw = torch.empty_like(w32)
+        _lib.check(lib.aecf_curriculum_mask_backward(rows, L, mode, eps, _ptr(w32), _ptr(bits), _ptr(dm), _ptr(de),
+                                                     _ptr(dw), _stream()), "aecf_curriculum_mask_backward")
+        return dw.to(wdt), None, None, None, None, None, None
+
+
+class _EntropyLossFunction(torch.autograd.Function):
+    """aecf_entropy_loss_fwd_bwd: the loss and its gradient come out of one launch pair."""
+
+    @staticmethod
+    def forward(ctx, entropy, last_seq_len, entropy_target):
+        lib = _lib.load()
+        e32 = entropy.detach().to(torch.float32).contiguous()
+        n = e32.numel()
+        dev = entropy.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dent = torch.empty_like(e32)
+        ws = torch.empty(lib.aecf_entropy_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(lib.aecf_entropy_loss_fwd_bwd(n, last_seq_len, entropy_target, _ptr(e32), 1.0, _ptr(loss),
+                                                 _ptr(dent), _ptr(ws), _stream()), "aecf_entropy_loss_fwd_bwd")
+        ctx.save_for_backward(dent)
+        ctx.edtype = entropy.dtype
+        return loss.reshape(()).to(entropy.dtype)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dent,) = ctx.saved_tensors
+        return (dent * dloss.to(torch.float32)).to(ctx.edtype), None, None
+
+
+class _SdpaFunction(torch.autograd.Function):
+    """aecf_sdpa_forward / _backward (projection-free single-head attention, ref :556-581)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        lib = _lib.load()
+        B, S, E = q.shape
+        T = k.shape[1]
+        dt = q.dtype
+        qc, kc, vc = q.contiguous(), k.to(dt).contiguous(), v.to(dt).contiguous()
+        out = torch.empty(B, S, E, dtype=dt, device=q.device)
+        probs = torch.empty(B, S, T, dtype=torch.float32, device=q.device)
+        _lib.check(lib.aecf_sdpa_forward(B, S, T, E, _DTYPES[dt], scale, _ptr(qc), _ptr(kc), _ptr(vc), _ptr(out),
+                                         _ptr(probs), _stream()), "aecf_sdpa_forward")
+        ctx.save_for_backward(qc, kc, vc, probs)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        qc, kc, vc, probs = ctx.saved_tensors
+        B, S, E = qc.shape
+        T = kc.shape[1]
+        dt = qc.dtype
+        do = dout.to(dt).contiguous()
+        dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+        _lib.check(lib.aecf_sdpa_backward(B, S, T, E, _DTYPES[dt], ctx.scale, _ptr(qc), _ptr(kc), _ptr(vc), _ptr(probs),
+                                          _ptr(do), _ptr(dq), _ptr(dk), _ptr(dv), _stream()), "aecf_sdpa_backward")
+        return dq, dk, dv, None
+
+
+# ----------------------------------------------------------------------------------------------
+# ref: aecf/AECFLayer.py:33-319
+# ----------------------------------------------------------------------------------------------
+class CurriculumMasking(nn.Module):
+    r"""Entropy-driven curriculum masking for attention weights (ref: aecf/AECFLayer.py:33-319).
+
+    Same constructor, ``forward`` contract and ``entropy_loss`` as the reference.  The Bernoulli
+    draw of ref :204 is made with one float32 uniform per weight element from torch's default
+    generator of the weights' device (``mask = U < keep_prob``), so the generator advances by
+    exactly ``weights.numel()`` draws as ``torch.bernoulli`` would.
+    """
+
+    def __init__(self, base_mask_prob: float = 0.15, entropy_target: float = 0.7, min_active: int = 1):
+        super().__init__()
+        if not 0.0 < base_mask_prob <= 1.0:                                   # ref :84-89
+            raise ValueError(f"base_mask_prob must be in (0, 1], got {base_mask_prob}")
+        if not 0.0 < entropy_target <= 1.0:
+            raise ValueError(f"entropy_target must be in (0, 1], got {entropy_target}")
+        if min_active < 1:
+            raise ValueError(f"min_active must be >= 1, got {min_active}")
+        self.base_mask_prob = base_mask_prob
+        self.entropy_target = entropy_target
+        self.min_active = min_active
+        self.register_buffer('_eps', torch.tensor(1e-8))                      # ref :96
+        self._last_seq_len = 2                                                # ref :99
+
+    def _mode(self) -> int:
+        return 1 if self.training else 2
+
+    def compute_entropy(self, weights: torch.Tensor) -> torch.Tensor:
+        """ref :101-128 -- Shannon entropy of the rows, clamped to [0, log L]."""
+        return self.compute_entropy_fused(weights)
+
+    def compute_entropy_fused(self, weights: torch.Tensor) -> torch.Tensor:
+        _require_device(weights, "weights")
+        _, entropy, _ = _MaskFunction.apply(weights, None, 2, self.min_active, float(self.base_mask_prob),
+                                            float(self.entropy_target), 1e-8)
+        return entropy.to(weights.dtype)
+
+    def forward(self, weights: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """ref :130-283."""
+        _require_device(weights, "weights")
+        dt = weights.dtype
+        seq_len = weights.size(-1)
+        if not self.training:                                                 # ref :150-156
+            _, entropy, mask_rate = _MaskFunction.apply(weights, None, 2, self.min_active,
+                                                        float(self.base_mask_prob), float(self.entropy_target), 1e-8)
+            return weights, {'entropy': entropy.to(dt), 'mask_rate': mask_rate.to(dt)}
+        if seq_len <= 1:                                                      # ref :160-167
+            z = torch.zeros(weights.shape[:-1], device=weights.device, dtype=dt)
+            return weights, {'entropy': z, 'mask_rate': z.clone(), 'target_entropy': z.clone()}
+        uniforms = _draw_uniforms(tuple(weights.shape), weights.device)                      # ref :204
+        masked, entropy, mask_rate = _MaskFunction.apply(weights, uniforms, 1, self.min_active,
+                                                         float(self.base_mask_prob), float(self.entropy_target), 1e-8)
+        self._last_seq_len = seq_len                                          # ref :187
+        entropy = entropy.to(dt)
+        info = {
+            'entropy': entropy,
+            'mask_rate': mask_rate,                                           # always float32 (ref :275)
+            'target_entropy': torch.full_like(entropy, math.log(float(seq_len)) * self.entropy_target),
+        }
+        return masked.to(dt), info
+
+    def entropy_loss(self, entropy: torch.Tensor) -> torch.Tensor:
+        """ref :285-314 -- MSE between entropy and log(L_last) * entropy_target."""
+        _require_device(entropy, "entropy")
+        seq_len = self._last_seq_len if hasattr(self, '_last_seq_len') else 2
+        return _EntropyLossFunction.apply(entropy, int(seq_len), float(self.entropy_target))
+
+    def extra_repr(self) -> str:                                              # ref :316-319
+        return (f'base_mask_prob={self.base_mask_prob}, '
+                f'entropy_target={self.entropy_target}, '
+                f'min_active={self.min_active}')
+
+
+# ----------------------------------------------------------------------------------------------
+# ref: aecf/AECFLayer.py:322-552
+# ----------------------------------------------------------------------------------------------
+def _shared_query_base(query: torch.Tensor) -> Optional[torch.Tensor]:
+    """If ``query`` is ``p.expand(B, -1, -1)`` of a [1,1,E] tensor (ref :694-695), return p so the gradient
+    reaches it directly (no [B,1,E] gradient is ever materialised)."""
+    B, T, E = query.shape
+    if T != 1:
+        return None
+    if B > 1 and query.stride(0) != 0:
+        return None
+    base = query._base if query._is_view() else None
+    if base is not None and base.dim() == 3 and tuple(base.shape) == (1, 1, E) and base.stride(-1) == query.stride(-1):
+        return base
+    return query[:1]
+
+
+class MultimodalAttentionPool(nn.Module):
+    r"""Multimodal attention pooling with optional curriculum masking (ref: aecf/AECFLayer.py:322-552).
+
+    Parameters live in a real ``torch.nn.MultiheadAttention`` under ``self.attention`` (same init RNG
+    order and state_dict keys as the reference); its ``forward`` is never called -- the arithmetic runs
+    in ``libaecf_hip.so``.
+
+    Built natively: one query shared by the batch (``fusion_query.expand(B, -1, -1)``, tgt_len 1),
+    ``value is key``, optional ``key_padding_mask``, dropout 0, bf16 or fp32.  Other argument
+    combinations raise NotImplementedError (they are not silently routed to PyTorch).
+    """
+
+    def __init__(self, embed_dim: int, num_heads: int = 1, dropout: float = 0.0, bias: bool = True,
+                 curriculum_masking: Optional[CurriculumMasking] = None, batch_first: bool = True,
+                 device: Optional[torch.device] = None, dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        if embed_dim <= 0:                                                    # ref :384-391
+            raise ValueError(f"embed_dim must be positive, got {embed_dim}")
+        if num_heads <= 0:
+            raise ValueError(f"num_heads must be positive, got {num_heads}")
+        if embed_dim % num_heads != 0:
+            raise ValueError(f"embed_dim ({embed_dim}) must be divisible by num_heads ({num_heads})")
+        if not 0.0 <= dropout <= 1.0:
+            raise ValueError(f"dropout must be in [0, 1], got {dropout}")
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.batch_first = batch_first
+        self.curriculum_masking = curriculum_masking
+        self.attention = nn.MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads, dropout=dropout,    # ref :399-407
+                                               bias=bias, batch_first=batch_first, device=device, dtype=dtype)
+
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: Optional[torch.Tensor] = None,
+                key_padding_mask: Optional[torch.Tensor] = None, attn_mask: Optional[torch.Tensor] = None,
+                return_info: bool = False, use_checkpoint: bool = False,
+                ) -> Union[torch.Tensor, Tuple[torch.Tensor, Dict[str, Any]]]:
+        # type / shape validation: ref :450-498 (messages identical)
+        if not isinstance(query, torch.Tensor):
+            raise TypeError(f"Expected query to be torch.Tensor, got {type(query)}")
+        if not isinstance(key, torch.Tensor):
+            raise TypeError(f"Expected key to be torch.Tensor, got {type(key)}")
+        if value is not None and not isinstance(value, torch.Tensor):
+            raise TypeError(f"Expected value to be torch.Tensor or None, got {type(value)}")
+        if value is None:
+            value = key
+        if self.batch_first:
+            if query.dim() != 3:
+                raise ValueError(f"Expected 3D query tensor with batch_first=True, got {query.dim()}D")
+            if key.dim() != 3:
+                raise ValueError(f"Expected 3D key tensor with batch_first=True, got {key.dim()}D")
+            if value.dim() != 3:
+                raise ValueError(f"Expected 3D value tensor with batch_first=True, got {value.dim()}D")
+            batch_size, tgt_len, embed_dim = query.shape
+            src_len = key.shape[1]
+            if src_len == 0:
+                raise ValueError("Key sequence length cannot be zero")
+            if key.shape[0] != batch_size or key.shape[2] != embed_dim:
+                raise RuntimeError(f"Key shape {key.shape} incompatible with query shape {query.shape}")
+            if value.shape[0] != batch_size or value.shape[1] != key.shape[1] or value.shape[2] != embed_dim:
+                raise RuntimeError(f"Value shape {value.shape} incompatible with key shape {key.shape}")
+        else:
+            if query.dim() != 3:
+                raise ValueError(f"Expected 3D query tensor with batch_first=False, got {query.dim()}D")
+            if key.dim() != 3:
+                raise ValueError(f"Expected 3D key tensor with batch_first=False, got {key.dim()}D")
+            if value.dim() != 3:
+                raise ValueError(f"Expected 3D value tensor with batch_first=False, got {value.dim()}D")
+            tgt_len, batch_size, embed_dim = query.shape
+            src_len = key.shape[0]
+            if src_len == 0:
+                raise ValueError("Key sequence length cannot be zero")
+            if key.shape[1] != batch_size or key.shape[2] != embed_dim:
+                raise RuntimeError(f"Shape mismatch: query {query.shape}, key {key.shape}")
+            if value.shape[0] != src_len or value.shape[1] != batch_size or value.shape[2] != embed_dim:
+                raise RuntimeError(f"Value shape {value.shape} incompatible with key shape {key.shape}")
+        if embed_dim != self.embed_dim:
+            raise AssertionError(f"was expecting embedding dimension of {self.embed_dim}, but got {embed_dim}")
+
+        _require_device(key, "key")
+        _require_device(query, "query")
+        same_kv = (value is key) or (value.data_ptr() == key.data_ptr() and value.shape == key.shape
+                                     and value.stride() == key.stride())
+        if not same_kv:
+            raise NotImplementedError("aecf_amd: value must be the key tensor (modalities attend to themselves)")
+        if attn_mask is not None:
+            raise NotImplementedError("aecf_amd: attn_mask is not supported by the HIP fusion path")
+        if self.attention.dropout > 0.0 and self.training:
+            raise NotImplementedError("aecf_amd: attention dropout > 0 in training mode is not supported")
+        if key.dtype not in _DTYPES:
+            raise NotImplementedError(f"aecf_amd: dtype {key.dtype} is not supported (bfloat16 / float32 only)")
+
+        # to batch-first [B, M, E] / [B, 1, E] (ref: torch activation.py:1453-1463 does the inverse)
+        if self.batch_first:
+            q_bf, x = query, key
+        else:
+            q_bf, x = query.transpose(0, 1), key.transpose(0, 1)
+        q_base = _shared_query_base(q_bf)
+        if q_base is None:
+            raise NotImplementedError(
+                "aecf_amd: the HIP path needs ONE query shared by the batch, i.e. fusion_query.expand(B, -1, -1) "
+                "with tgt_len 1 (ref aecf/AECFLayer.py:694-695)")
+        kpm = None
+        if key_padding_mask is not None:
+            if key_padding_mask.shape != (batch_size, src_len):
+                raise RuntimeError(f"key_padding_mask shape {tuple(key_padding_mask.shape)} != {(batch_size, src_len)}")
+            kpm = key_padding_mask.to(device=x.device, dtype=torch.uint8).contiguous()
+
+        cm = self.curriculum_masking
+        mask_mode = 0
+        uniforms = None
+        if cm is not None:
+            mask_mode = 1 if cm.training else 2
+            if mask_mode == 1 and src_len <= 1:
+                mask_mode = 0          # ref :160-167 early-out: handled on the host below
+            if mask_mode == 1:
+                # one float32 uniform per weight element, row-major, default generator (ref :204)
+                uniforms = _draw_uniforms((batch_size, tgt_len, src_len), x.device)
+        a = self.attention
+        y, attn_w, masked_w, entropy, mask_rate = _PoolFunction.apply(
+            x, q_base, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, kpm, uniforms,
+            self.num_heads, mask_mode, 1 if cm is None else int(cm.min_active),
+            0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8)
+
+        dt = x.dtype
+        attn_output = y.unsqueeze(1) if self.batch_first else y.unsqueeze(0)          # [B,1,E] / [1,B,E]
+        attn_weights = attn_w.to(dt).unsqueeze(1)                                    # [B,1,M] (always batch-major)
+
+        info: Dict[str, Any] = {}
+        if cm is not None:                                                           # ref :526-541
+            if cm.training and src_len <= 1:
+                z = torch.zeros(batch_size, tgt_len, device=x.device, dtype=dt)
+                mask_info = {'entropy': z, 'mask_rate': z.clone(), 'target_entropy': z.clone()}
+                masked_weights = attn_weights
+            elif cm.training:
+                cm._last_seq_len = src_len                                           # ref :187
+                ent = entropy.to(dt).unsqueeze(1)
+                mask_info = {
+                    'entropy': ent,
+                    'mask_rate': mask_rate.unsqueeze(1),                             # float32 (ref :275)
+                    'target_entropy': torch.full_like(ent, math.log(float(src_len)) * cm.entropy_target),
+                }
+                masked_weights = masked_w.to(dt).unsqueeze(1)
+            else:
+                mask_info = {'entropy': entropy.to(dt).unsqueeze(1), 'mask_rate': mask_rate.to(dt).unsqueeze(1)}
+                masked_weights = attn_weights
+            info.update(mask_info)
+            info['attention_weights'] = attn_weights
+            if return_info:
+                info['masked_attention_weights'] = masked_weights.detach()
+        elif return_info:
+            info['attention_weights'] = attn_weights
+        if return_info:
+            return attn_output, info
+        return attn_output
+
+    def extra_repr(self) -> str:                                              # ref :549-552
+        return (f'embed_dim={self.embed_dim}, num_heads={self.num_heads}, '
+                f'batch_first={self.batch_first}, '
+                f'curriculum_masking={self.curriculum_masking is not None}')
+
+
+# ----------------------------------------------------------------------------------------------
+# ref: aecf/AECFLayer.py:556-652
+# ----------------------------------------------------------------------------------------------
+def _scaled_dot_product_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                                  scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(Q K^T * scale) V without projections (ref :556-581), HIP kernel."""
+    _require_device(query, "query")
+    if query.dtype not in _DTYPES:
+        raise NotImplementedError(f"aecf_amd: dtype {query.dtype} is not supported (bfloat16 / float32 only)")
+    if scale is None:
+        scale = query.size(-1) ** -0.5
+    return _SdpaFunction.apply(query, key, value, float(scale))
+
+
+def multimodal_attention_pool(query: torch.Tensor, key: torch.Tensor, value: Optional[torch.Tensor] = None,
+                              embed_dim: Optional[int] = None, num_heads: int = 1, dropout: float = 0.0,
+                              curriculum_masking: Optional[CurriculumMasking] = None,
+                              training: bool = False) -> torch.Tensor:
+    """Functional interface (ref :584-652): projection-free fast path, else a fresh randomly
+    initialised MultimodalAttentionPool per call (initialised on the CPU generator exactly like the
+    reference, then moved to the query's device)."""
+    if embed_dim is None:
+        embed_dim = query.size(-1)
+    if value is None:
+        value = key
+    if (not training and curriculum_masking is None and dropout == 0.0 and num_heads == 1):   # ref :638-640
+        return _scaled_dot_product_attention(query, key, value)
+    pool = MultimodalAttentionPool(embed_dim=embed_dim, num_heads=num_heads, dropout=dropout,
+                                   curriculum_masking=curriculum_masking, batch_first=True)
+    pool = pool.to(device=query.device)
+    pool.train(training)
+    return pool(query, key, value)
+
+
+# ----------------------------------------------------------------------------------------------
+# ref: aecf/AECFLayer.py:655-728
+# ----------------------------------------------------------------------------------------------
+def create_fusion_pool(embed_dim: int, num_modalities: int, mask_prob: float = 0.15,
+                       **kwargs) -> Tuple[nn.Parameter, MultimodalAttentionPool]:
+    """Factory (ref :655-728): ``(fusion_query ~ N(0, 2/E) of shape [1,1,E], pool with curriculum masking)``."""
+    if not isinstance(embed_dim, int) or embed_dim <= 0:                      # ref :706-711
+        raise ValueError(f"embed_dim must be a positive integer, got {embed_dim}")
+    if not isinstance(num_modalities, int) or num_modalities <= 0:
+        raise ValueError(f"num_modalities must be a positive integer, got {num_modalities}")
+    if not isinstance(mask_prob, (int, float)) or not (0.0 < mask_prob <= 1.0):
+        raise ValueError(f"mask_prob must be in (0, 1], got {mask_prob}")
+    fusion_query = nn.Parameter(torch.empty(1, 1, embed_dim))                 # ref :714-716
+    nn.init.normal_(fusion_query, 0.0, (2.0 / embed_dim) ** 0.5)
+    curriculum_masking = CurriculumMasking(base_mask_prob=mask_prob)          # ref :719
+    attention_pool = MultimodalAttentionPool(embed_dim=embed_dim, curriculum_masking=curriculum_masking, **kwargs)
+    return fusion_query, attention_pool

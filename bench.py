@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- fused samples/sec (forward+backward) of the AECF fusion path on N MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched with torch.distributed.run, one rank
+per GPU over RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on): synthetic
+x[B=65536, M=3, d=512] bf16, 8 heads, mask_prob 0.15, curriculum masking in training mode.
+One "step" = pool(query.expand(B), x, return_info=True) + entropy_loss(info['entropy']) + backward with a
+resident upstream gradient dy, all inputs resident in HBM.  N>1: every rank runs its own B samples (weak
+scaling) and the parameter gradients (4E^2+5E floats) are all-reduced over RCCL inside the step.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (B per GPU, M, E, H, dtype, mask_prob)
+    "c2": (65536, 3, 512, 8, torch.bfloat16, 0.15),
+    "c5": (16384, 4, 1024, 8, torch.bfloat16, 0.15),      # configs[4] per-GPU shard (B=131072 / 8)
+    "c3": (8192, 2, 768, 8, torch.bfloat16, 0.15),
+    "tiny": (4096, 3, 128, 4, torch.bfloat16, 0.15),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16
+
+
+def make_inputs(cfg, device):
+    B, M, E, H, dtype, p = cfg
+    import aecf_amd
+    torch.manual_seed(2)
+    query, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=p, num_heads=H)
+    with torch.no_grad():
+        pool.attention.in_proj_bias.normal_(0.0, 0.02)
+        pool.attention.out_proj.bias.normal_(0.0, 0.02)
+        query.copy_(torch.randn(1, 1, E, generator=torch.Generator().manual_seed(1)) * (2.0 / E) ** 0.5)
+    pool = pool.to(device=device, dtype=dtype)
+    query = torch.nn.Parameter(query.detach().to(device=device, dtype=dtype))
+    g = torch.Generator(device=device).manual_seed(0)
+    x = torch.randn(B, M, E, device=device, generator=g).to(dtype).requires_grad_(True)
+    dy = torch.randn(B, 1, E, device=device, generator=g).to(dtype)
+    pool.train()
+    return pool, query, x, dy
+
+
+def step(pool, query, x, dy, params, world):
+    B = x.shape[0]
+    out, info = pool(query.expand(B, -1, -1), x, return_info=True)
+    ent_loss = pool.curriculum_masking.entropy_loss(info["entropy"])
+    for p in params:
+        p.grad = None
+    x.grad = None
+    torch.autograd.backward([out], [dy])
+    if world > 1:
+        import torch.distributed as dist
+        flat = torch.cat([p.grad.reshape(-1).float() for p in params])
+        dist.all_reduce(flat)
+        flat.div_(world)
+    return out, ent_loss
+
+
+class StageTimer:
+    """hipEvents recorded by the library at its stage boundaries (include/aecf_hip.h profiling hook)."""
+
+    def __init__(self):
+        from aecf_amd import _lib
+        self._lib = _lib
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.nf, self.nb = _lib.AECF_FWD_STAGES, _lib.AECF_BWD_STAGES
+        self.fwd = (ctypes.c_void_p * (self.nf + 1))()
+        self.bwd = (ctypes.c_void_p * (self.nb + 1))()
+        for arr in (self.fwd, self.bwd):
+            for i in range(len(arr)):
+                ev = ctypes.c_void_p()
+                assert self.hip.hipEventCreate(ctypes.byref(ev)) == 0
+                arr[i] = ev
+        lib = _lib.load()
+        self.names = [("fwd." + lib.aecf_pool_stage_name(0, i).decode()) for i in range(self.nf)] + \
+                     [("bwd." + lib.aecf_pool_stage_name(1, i).decode()) for i in range(self.nb)]
+        self.acc = [0.0] * (self.nf + self.nb)
+        self.n = 0
+
+    def arm(self):
+        self._lib.stage_events_fwd = self.fwd
+        self._lib.stage_events_bwd = self.bwd
+
+    def disarm(self):
+        self._lib.stage_events_fwd = None
+        self._lib.stage_events_bwd = None
+
+    def collect(self):
+        ms = ctypes.c_float()
+        k = 0
+        for arr in (self.fwd, self.bwd):
+            for i in range(len(arr) - 1):
+                assert self.hip.hipEventElapsedTime(ctypes.byref(ms), arr[i], arr[i + 1]) == 0
+                self.acc[k] += ms.value
+                k += 1
+        self.n += 1
+
+    def mean_ms(self):
+        return {n: a / max(self.n, 1) for n, a in zip(self.names, self.acc)}
+
+
+def stage_model(cfg):
+    """Algorithmic HBM bytes and MFMA flops per sample of each stage."""
+    B, M, E, H, dtype, _ = cfg
+    s = 2 if dtype == torch.bfloat16 else 4
+    return {
+        "fwd.gate":    dict(bytes=s * M * E, flops=2 * M * E * 16 * (2 if s == 2 else 1)),
+        "fwd.vproj":   dict(bytes=s * (M + 1) * E, flops=2 * E * E),
+        "fwd.outproj": dict(bytes=s * 2 * E, flops=2 * E * E),
+        "bwd.dout":    dict(bytes=s * 2 * E, flops=2 * E * E),
+        "bwd.dw_out":  dict(bytes=s * 2 * E, flops=2 * E * E),
+        "bwd.dscore":  dict(bytes=s * (M + 1) * E, flops=2 * E * E),
+        "bwd.dx":      dict(bytes=s * (M + 1) * E, flops=2 * E * E),
+        "bwd.dw_v":    dict(bytes=s * (M + 1) * E, flops=2 * E * E),
+    }
+
+
+def cpu_baseline(cfg, seconds_budget=20.0):
+    """The CPU oracle (oracle/aecf_oracle.py, a port of the reference's arithmetic) timed on this box's host
+    cores on a bounded sample of the same workload: fp32, forward + explicit backward."""
+    from oracle import aecf_oracle as O
+    B, M, E, H, dtype, p = cfg
+    n = min(B, 8192)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, M, E, generator=g)
+    q = torch.randn(1, 1, E, generator=g) * (2.0 / E) ** 0.5
+    w_in = torch.randn(3 * E, E, generator=g) / E ** 0.5
+    b_in = torch.randn(3 * E, generator=g) * 0.02
+    w_out = torch.randn(E, E, generator=g) / E ** 0.5
+    b_out = torch.randn(E, generator=g) * 0.02
+    dy = torch.randn(n, 1, E, generator=g)
+    U = torch.rand(n, 1, M, generator=g)
+
+    def one():
+        qe = q.expand(n, -1, -1)
+        f = O.mha_forward(qe, x, x, w_in, b_in, w_out, b_out, H)
+        m = O.curriculum_mask_train(f["wbar"], U, p)
+        O.entropy_loss(m["entropy"], M)
+        O.mha_backward(qe, x, x, w_in, b_in, w_out, H, f, dy, None)
+
+    one()
+    best, reps, t_all = 1e30, 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t_all < seconds_budget and reps < 20):
+        t0 = time.perf_counter()
+        one()
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    return dict(value=n / best, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} samples of the same [B,M={M},d={E}] workload, fp32, fwd+bwd, best of {reps}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    cfg = CONFIGS[args.config]
+    B, M, E, H, dtype, p = cfg
+    pool, query, x, dy = make_inputs(cfg, device)
+    params = [query] + list(pool.parameters())
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(pool, query, x, dy, params, world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(pool, query, x, dy, params, world)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-stage durations (HIP events on the launch stream), measured live over extra steps after the timed region
+    roofline = None
+    stages = None
+    if rank == 0:
+        st = StageTimer()
+        for _ in range(min(args.steps, 20)):
+            st.arm()
+            step(pool, query, x, dy, params, 1)
+            st.disarm()
+            torch.cuda.synchronize()
+            st.collect()
+        stages = st.mean_ms()
+        model = stage_model(cfg)
+        dom = max((k for k in stages if k in model), key=lambda k: stages[k])
+        t_s = stages[dom] * 1e-3
+        gbs = model[dom]["bytes"] * B / t_s / 1e9
+        tfl = model[dom]["flops"] * B / t_s / 1e12
+        if gbs / HBM_PEAK_GBS >= tfl / MFMA_PEAK_TFLOPS:
+            roofline = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                            traffic=None, kernel=dom, kernel_ms=stages[dom])
+        else:
+            roofline = dict(bound="mfma", achieved=tfl, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=tfl / MFMA_PEAK_TFLOPS, traffic=None, kernel=dom, kernel_ms=stages[dom])
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        s_bytes = 2 if dtype == torch.bfloat16 else 4
+        path_bytes = s_bytes * E * (3 * M + 2)
+        line = {
+            "metric": "fused samples/sec (fwd+bwd)", "value": world * B / (elapsed / args.steps), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: [B={B} per GPU, M={M}, d={E}, {H} heads] mask_prob={p} "
+                                   "train-mode curriculum masking, fwd+bwd", "global_batch": world * B,
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline,
+            "path_hbm_frac": path_bytes * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "stage_ms": stages,
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(cfg),
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

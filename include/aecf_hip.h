@@ -1,0 +1,167 @@
+/*
+ * aecf_hip.h -- C ABI of libaecf_hip.so: the MI355X (gfx950) implementation of the AECF
+ * fusion hot path (BASELINE.json north_star).
+ *
+ * The reference (leochlon/aecf) is pure Python and has no FFI of its own: its boundary for
+ * this path is the Python API in aecf/AECFLayer.py.  Each entry point below replaces the
+ * arithmetic of one reference function; the Python package aecf_amd/ binds these symbols
+ * with ctypes and mirrors the reference's signatures (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - plain C symbols, plain pointers and sizes, no C++/torch types.
+ *  - the CALLER owns every buffer (including the workspace); the library never allocates,
+ *    frees or retains device memory, never synchronises the stream and never throws.
+ *  - every call only enqueues kernels on `stream` (a hipStream_t passed as void*).
+ *  - return value: AECF_OK (0) or a negative aecf_status.
+ *  - dtype: AECF_BF16 or AECF_F32 for x / query / weights / y.  All statistics
+ *    (attention weights, entropy, mask rate, saved probabilities) and all parameter
+ *    gradients are float32.
+ *  - re-entrant; no global mutable state.
+ */
+#ifndef AECF_HIP_H
+#define AECF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AECF_ABI_VERSION 1
+
+typedef enum aecf_status {
+    AECF_OK = 0,
+    AECF_ERR_BAD_DIMS = -1,        /* non-positive size, E % num_heads != 0, ...            */
+    AECF_ERR_UNSUPPORTED = -2,     /* valid for the reference but not built here (see msg)  */
+    AECF_ERR_NULL_POINTER = -3,
+    AECF_ERR_WORKSPACE = -4,       /* workspace too small                                    */
+    AECF_ERR_LAUNCH = -5           /* hipGetLastError() != hipSuccess after a launch         */
+} aecf_status;
+
+typedef enum aecf_dtype { AECF_BF16 = 0, AECF_F32 = 1 } aecf_dtype;
+
+/* Problem description shared by forward and backward.
+ * Replaces: MultimodalAttentionPool.__init__/forward shape contract
+ * (ref aecf/AECFLayer.py:371-407, 461-498) for the hot-path case
+ *   query = fusion_query.expand(B,1,E)  (one shared query, ref :694-695),
+ *   key is value = x[B,M,E] contiguous, batch_first, dropout 0, no attn_mask. */
+typedef struct aecf_pool_desc {
+    int64_t batch;        /* B                                   */
+    int32_t modalities;   /* M = src_len, 1..8                    */
+    int32_t embed_dim;    /* E, multiple of 64                    */
+    int32_t num_heads;    /* H, 1..16, E % H == 0, (E/H) % 32 == 0 (bf16) or % 16 == 0 (f32) */
+    int32_t dtype;        /* aecf_dtype of x/query/weights/y      */
+    /* curriculum masking (ref aecf/AECFLayer.py:76-99); mask_mode 0 = no CurriculumMasking
+     * module attached, 1 = training-mode masking (:158-283), 2 = eval-mode (:150-156)      */
+    int32_t mask_mode;
+    int32_t min_active;
+    float base_mask_prob;
+    float entropy_target;
+    float eps;            /* the module's _eps buffer, 1e-8 (:96) */
+} aecf_pool_desc;
+
+/* Forward.  Replaces nn.MultiheadAttention math (torch functional.py:5836-5852, 6576-6612,
+ * called at ref :515-521) + CurriculumMasking.forward (ref :130-283) on the head-averaged
+ * weights, fused.  Outputs other than y are float32. */
+typedef struct aecf_pool_fwd_args {
+    const void* x;               /* [B,M,E] dtype                                        */
+    const void* query;           /* [E] dtype: the shared fusion query                   */
+    const void* w_in;            /* [3E,E] dtype  (in_proj_weight, q|k|v)                */
+    const void* b_in;            /* [3E] dtype or NULL                                   */
+    const void* w_out;           /* [E,E] dtype   (out_proj.weight)                      */
+    const void* b_out;           /* [E] dtype or NULL                                    */
+    const uint8_t* key_padding_mask; /* [B,M] nonzero = ignore, or NULL                  */
+    const float* uniforms;       /* [B,M] float32 U[0,1) (mask_mode 1) or NULL           */
+    void* y;                     /* [B,E] dtype                                          */
+    float* attn_w;               /* [B,M] head-averaged weights (info['attention_weights']) */
+    float* masked_w;             /* [B,M] or NULL                                        */
+    float* entropy;              /* [B]   or NULL                                        */
+    float* mask_rate;            /* [B]   or NULL                                        */
+    float* saved_probs;          /* [B,H,M] per-head softmax, saved for backward         */
+    void* saved_o;               /* [B,E] dtype: pre-out-projection heads, saved for backward (or NULL) */
+    void* workspace;
+    size_t workspace_bytes;
+    /* optional profiling hook: AECF_FWD_STAGES+1 hipEvent_t handles (caller-created); event[0] is recorded
+     * before the first kernel and event[i] after stage i (see aecf_pool_stage_name). NULL = off. */
+    void** stage_events;
+} aecf_pool_fwd_args;
+
+/* Backward (autograd transpose of the above). */
+typedef struct aecf_pool_bwd_args {
+    const void* x;
+    const void* query;
+    const void* w_in;
+    const void* b_in;
+    const void* w_out;
+    const void* dy;              /* [B,E] dtype                                          */
+    const float* d_attn_w;       /* [B,M] grad on info['attention_weights'] or NULL      */
+    const float* d_entropy;      /* [B] grad on info['entropy'] (eval mode only) or NULL */
+    const float* attn_w;         /* [B,M] forward output (needed with d_entropy)         */
+    const float* saved_probs;    /* [B,H,M]                                              */
+    const void* saved_o;         /* [B,E]                                                */
+    void* dx;                    /* [B,M,E] dtype                                        */
+    float* dquery;               /* [E]                                                  */
+    float* dw_in;                /* [3E,E]                                               */
+    float* db_in;                /* [3E]                                                 */
+    float* dw_out;               /* [E,E]                                                */
+    float* db_out;               /* [E]                                                  */
+    void* workspace;
+    size_t workspace_bytes;
+    void** stage_events;         /* AECF_BWD_STAGES+1 hipEvent_t handles or NULL (profiling hook) */
+} aecf_pool_bwd_args;
+
+#define AECF_FWD_STAGES 4   /* prep, gate, vproj, outproj */
+#define AECF_BWD_STAGES 7   /* prep, dout, dw_out, dscore, dx, dw_v, finalize */
+
+int aecf_abi_version(void);
+/* name of forward (backward == 0) or backward stage i, or NULL when out of range */
+const char* aecf_pool_stage_name(int backward, int stage);
+const char* aecf_status_string(int status);
+
+/* validates the description; returns AECF_OK or the reason it cannot run */
+int aecf_pool_check(const aecf_pool_desc* d);
+/* scratch bytes needed by forward / backward for this description */
+size_t aecf_pool_fwd_workspace_bytes(const aecf_pool_desc* d);
+size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d);
+
+int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream);
+int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream);
+
+/* Stand-alone CurriculumMasking.forward on rows of length L (ref aecf/AECFLayer.py:130-283).
+ * weights [rows,L] float32.  mode 1 = train (uniforms required), 2 = eval.
+ * Any output pointer may be NULL. */
+int aecf_curriculum_mask_forward(int64_t rows, int32_t L, int32_t mode, int32_t min_active,
+                                 float base_mask_prob, float entropy_target, float eps,
+                                 const float* weights, const float* uniforms,
+                                 float* masked, float* entropy, float* mask_rate,
+                                 uint8_t* mask_bits, void* stream);
+
+/* Gradient of the stand-alone module's masked output and (eval mode) entropy w.r.t. weights.
+ * d_masked [rows,L] or NULL, d_entropy [rows] or NULL, mask_bits from the forward (train). */
+int aecf_curriculum_mask_backward(int64_t rows, int32_t L, int32_t mode, float eps,
+                                  const float* weights, const uint8_t* mask_bits,
+                                  const float* d_masked, const float* d_entropy,
+                                  float* d_weights, void* stream);
+
+/* CurriculumMasking.entropy_loss forward + backward (ref aecf/AECFLayer.py:285-314):
+ * loss[0] = mean((nan_to_num(H) - log(last_seq_len)*entropy_target)^2); d_entropy = dloss/dH * upstream.
+ * partial: scratch of aecf_entropy_loss_workspace_bytes(n). */
+size_t aecf_entropy_loss_workspace_bytes(int64_t n);
+int aecf_entropy_loss_fwd_bwd(int64_t n, int32_t last_seq_len, float entropy_target,
+                              const float* entropy, float upstream, float* loss,
+                              float* d_entropy, void* workspace, void* stream);
+
+/* Projection-free single-head attention softmax(Q K^T * scale) V (ref aecf/AECFLayer.py:556-581).
+ * q [B,S,E], k,v [B,T,E] dtype; out [B,S,E] dtype; probs [B,S,T] float32 saved for backward. */
+int aecf_sdpa_forward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype, float scale,
+                      const void* q, const void* k, const void* v, void* out, float* probs,
+                      void* stream);
+int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype, float scale,
+                       const void* q, const void* k, const void* v, const float* probs,
+                       const void* dout, void* dq, void* dk, void* dv, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AECF_HIP_H */

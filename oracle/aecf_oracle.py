@@ -199,6 +199,24 @@ def curriculum_mask_train(
                 target_entropy=target, weights_norm=w, keep=keep.squeeze(-1))
 
 
+def curriculum_mask_train_backward(weights: Tensor, mask: Tensor, d_masked: Tensor, eps: float = 1e-8) -> Tensor:
+    """Gradient of curriculum_mask_train()['masked'] w.r.t. ``weights`` (what autograd gives the
+    reference for the stand-alone module, ref :170-184, :263-272; entropy/keep-prob carry no gradient:
+    the Bernoulli draw cuts the graph and the info entries are detached, ref :277-281)."""
+    finite = torch.isfinite(weights)
+    w = torch.where(finite, weights, torch.zeros_like(weights))
+    s = w.sum(-1, keepdim=True)
+    needs_norm = s < eps
+    wn = w / s
+    ms = (wn * mask).sum(-1, keepdim=True)
+    final = wn * mask / ms
+    dot = (d_masked * final).sum(-1, keepdim=True)
+    dwn = torch.where(ms > eps, mask * (d_masked - dot) / ms, d_masked)
+    dot2 = (dwn * wn).sum(-1, keepdim=True)
+    dw = (dwn - dot2) / s
+    return torch.where(needs_norm | ~finite, torch.zeros_like(dw), dw)
+
+
 def curriculum_mask_eval(weights: Tensor) -> Dict[str, Tensor]:
     """Eval-mode branch, ref: aecf/AECFLayer.py:150-156: weights unchanged, no target key."""
     ent = entropy_rows(weights)

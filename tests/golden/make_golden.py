@@ -111,6 +111,12 @@ def g3_case(name, M, p_base, min_active, n=4096, seed=0, sharp=2.0, lead=(1,)):
     masked, info = mod(w)
     nxt = torch.rand(4)     # generator must have advanced by exactly w.numel() draws
     assert torch.equal(nxt, nxt_expected), "bernoulli consumed a different number of draws"
+    # gradient of the masked output w.r.t. the input weights (stand-alone module, train mode)
+    w_g = w.clone().requires_grad_(True)
+    gm = torch.randn(w.shape, generator=g)
+    torch.manual_seed(400 + seed)
+    masked_g, _ = mod(w_g)
+    (masked_g * gm).sum().backward()
     mask = (masked != 0)
     # where the reference fell back (all masked & sum<=eps) mask can't be read off `masked`; recover
     # the mask from mask_rate consistency instead: store what the reference exposes.
@@ -119,7 +125,8 @@ def g3_case(name, M, p_base, min_active, n=4096, seed=0, sharp=2.0, lead=(1,)):
         M=M, p_base=p_base, min_active=min_active, entropy_target=mod.entropy_target,
         weights=npy(w), uniforms=npy(U), masked=npy(masked), nonzero=npy(mask),
         entropy=npy(info["entropy"]), mask_rate=npy(info["mask_rate"]),
-        target_entropy=npy(info["target_entropy"]), last_seq_len=mod._last_seq_len)
+        target_entropy=npy(info["target_entropy"]), last_seq_len=mod._last_seq_len,
+        d_masked=npy(gm), d_weights=npy(w_g.grad))
     print("g3", name, "mask_rate", float(info["mask_rate"].mean()))
 
 
@@ -349,9 +356,11 @@ if __name__ == "__main__":
     g2_case("e64h4m3_kpm", 64, 4, 3, 64, seed=5, kpm=True)
     g2_case("e64h2m3_perq_t2", 64, 2, 3, 24, T=2, shared_query=False, seed=6)
     # bf16-representable inputs and weights (G6 protocol target = fp32 math on these)
-    g2_case("bf16_e64h4m3", 64, 4, 3, 64, seed=7, bf16_inputs=True)
-    g2_case("bf16_e128h8m4", 128, 8, 4, 40, seed=8, bf16_inputs=True)
-    g2_case("bf16_e128h8m2", 128, 8, 2, 72, seed=9, bf16_inputs=True)
+    # (head_dim is a multiple of 32: the bf16 MFMA K-step)
+    g2_case("bf16_e128h4m3", 128, 4, 3, 64, seed=7, bf16_inputs=True)
+    g2_case("bf16_e128h2m4", 128, 2, 4, 40, seed=8, bf16_inputs=True)
+    g2_case("bf16_e256h8m2", 256, 8, 2, 72, seed=9, bf16_inputs=True)
+    g2_case("bf16_e192h2m3_kpm", 192, 2, 3, 50, seed=10, bf16_inputs=True, kpm=True)
     for i, (M, p, k) in enumerate([(3, 0.15, 1), (3, 0.25, 1), (3, 1.0, 1), (4, 0.5, 2), (2, 0.15, 1),
                                    (4, 1.0, 1), (8, 0.6, 3)]):
         g3_case(f"m{M}_p{int(p * 100)}_k{k}", M, p, k, seed=i)

@@ -1,0 +1,149 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every declared symbol, the
+host mirror raises the reference's exceptions with the reference's messages, parameters are created in
+the reference's RNG order, and nothing silently falls back to a CPU path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import aecf_amd
+from aecf_amd import _lib
+from tests.helpers import ROOT, load_json, load_npz, t
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built_library():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(built_library):
+    header = open(os.path.join(ROOT, "include", "aecf_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(aecf_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no declarations found in include/aecf_hip.h"
+    assert sorted(_lib.SYMBOL_NAMES) == declared          # the binding covers exactly the header
+    for name in declared:
+        assert hasattr(built_library, name), f"libaecf_hip.so does not export {name}"
+    assert built_library.aecf_abi_version() == _lib.AECF_ABI_VERSION
+    assert _lib.status_string(0) == "ok"
+    assert "not supported" in _lib.status_string(-2)
+
+
+def test_struct_layout_matches_header():
+    # include/aecf_hip.h: aecf_pool_desc = int64 + 6*int32 + 3*float = 44 -> padded to 48
+    assert ctypes.sizeof(_lib.PoolDesc) == 48
+    assert ctypes.sizeof(_lib.PoolFwdArgs) == 18 * 8
+    assert ctypes.sizeof(_lib.PoolBwdArgs) == 20 * 8
+
+
+def test_pool_check_and_workspace_sizes(built_library):
+    def desc(B=65536, M=3, E=512, H=8, dtype=0, mode=1):
+        return _lib.PoolDesc(B, M, E, H, dtype, mode, 1, 0.15, 0.7, 1e-8)
+    d = desc()
+    assert built_library.aecf_pool_check(ctypes.byref(d)) == 0
+    fwd = built_library.aecf_pool_fwd_workspace_bytes(ctypes.byref(d))
+    bwd = built_library.aecf_pool_bwd_workspace_bytes(ctypes.byref(d))
+    assert 65536 * 512 * 2 <= fwd < 80 << 20
+    assert bwd < 400 << 20
+    assert built_library.aecf_pool_check(ctypes.byref(desc(H=7))) == -1            # E % H
+    assert built_library.aecf_pool_check(ctypes.byref(desc(M=9))) == -2            # too many modalities
+    assert built_library.aecf_pool_check(ctypes.byref(desc(E=96, H=2))) == -2      # E % 64
+    assert built_library.aecf_pool_check(ctypes.byref(desc(E=64, H=4))) == -2      # bf16 head_dim 16
+    assert built_library.aecf_pool_check(ctypes.byref(desc(E=64, H=4, dtype=1))) == 0
+    assert built_library.aecf_pool_check(ctypes.byref(desc(B=0))) == -1
+    # null pointers are rejected before anything is launched
+    assert built_library.aecf_pool_forward(ctypes.byref(d), ctypes.byref(_lib.PoolFwdArgs()), None) == -3
+    assert built_library.aecf_pool_backward(ctypes.byref(d), ctypes.byref(_lib.PoolBwdArgs()), None) == -3
+
+
+def test_validation_matches_reference_messages():
+    cases = {c["name"]: c for c in load_json("g9_validation.json")}
+    q = torch.zeros(4, 1, 8)
+    k = torch.zeros(4, 3, 8)
+    pool = aecf_amd.MultimodalAttentionPool(8, num_heads=2)
+    pool_sf = aecf_amd.MultimodalAttentionPool(8, num_heads=2, batch_first=False)
+    calls = {
+        "mask_prob_zero": lambda: aecf_amd.CurriculumMasking(base_mask_prob=0.0),
+        "mask_prob_big": lambda: aecf_amd.CurriculumMasking(base_mask_prob=1.5),
+        "entropy_target_zero": lambda: aecf_amd.CurriculumMasking(entropy_target=0.0),
+        "min_active_zero": lambda: aecf_amd.CurriculumMasking(min_active=0),
+        "embed_dim_neg": lambda: aecf_amd.MultimodalAttentionPool(-4),
+        "num_heads_zero": lambda: aecf_amd.MultimodalAttentionPool(8, num_heads=0),
+        "indivisible": lambda: aecf_amd.MultimodalAttentionPool(8, num_heads=3),
+        "dropout_bad": lambda: aecf_amd.MultimodalAttentionPool(8, dropout=1.5),
+        "query_type": lambda: pool([1, 2], k),
+        "key_type": lambda: pool(q, "k"),
+        "value_type": lambda: pool(q, k, 3),
+        "query_2d": lambda: pool(q[0], k),
+        "key_2d": lambda: pool(q, k[0]),
+        "value_2d": lambda: pool(q, k, k[0]),
+        "src_len_zero": lambda: pool(q, k[:, :0]),
+        "key_batch_mismatch": lambda: pool(q, k[:2]),
+        "key_embed_mismatch": lambda: pool(q, torch.zeros(4, 3, 6)),
+        "value_mismatch": lambda: pool(q, k, torch.zeros(4, 2, 8)),
+        "sf_query_2d": lambda: pool_sf(q[0], k),
+        "sf_src_len_zero": lambda: pool_sf(q.transpose(0, 1), k.transpose(0, 1)[:0]),
+        "sf_key_mismatch": lambda: pool_sf(q.transpose(0, 1), k.transpose(0, 1)[:, :2]),
+        "sf_value_mismatch": lambda: pool_sf(q.transpose(0, 1), k.transpose(0, 1), torch.zeros(2, 4, 8)),
+        "factory_embed_float": lambda: aecf_amd.create_fusion_pool(8.0, 2),
+        "factory_embed_zero": lambda: aecf_amd.create_fusion_pool(0, 2),
+        "factory_modalities_zero": lambda: aecf_amd.create_fusion_pool(8, 0),
+        "factory_mask_prob": lambda: aecf_amd.create_fusion_pool(8, 2, mask_prob=0.0),
+    }
+    assert set(calls) == set(cases)
+    for name, fn in calls.items():
+        want = cases[name]
+        assert want["type"] is not None, name
+        with pytest.raises(Exception) as ei:
+            fn()
+        assert type(ei.value).__name__ == want["type"], (name, ei.value)
+        assert str(ei.value) == want["msg"], name
+
+
+def test_public_surface_and_init_rng_order():
+    assert aecf_amd.__all__ == ["CurriculumMasking", "MultimodalAttentionPool", "multimodal_attention_pool",
+                                "create_fusion_pool"]
+    assert aecf_amd.__version__ == "0.1.0"
+    g = load_npz("g1_plumbing.npz")
+    torch.manual_seed(int(g["seed_init"]))
+    query, pool = aecf_amd.create_fusion_pool(embed_dim=512, num_modalities=2)
+    assert isinstance(query, torch.nn.Parameter) and query.shape == (1, 1, 512)
+    assert np.allclose(query.detach().numpy()[0, 0, :8], g["query_head"])
+    assert np.allclose(pool.attention.in_proj_weight.detach().numpy()[0, :8], g["w_in_head"])
+    assert np.allclose(pool.attention.out_proj.weight.detach().numpy()[0, :8], g["w_out_head"])
+    assert list(pool.state_dict().keys()) == list(g["sd_keys"])
+    assert pool.extra_repr() == str(g["repr_pool"])
+    assert pool.curriculum_masking.extra_repr() == str(g["repr_mask"])
+    assert pool.curriculum_masking._last_seq_len == 2
+    # a reference checkpoint loads unchanged (same key names and shapes)
+    sd = {k: torch.zeros_like(v) for k, v in pool.state_dict().items()}
+    pool.load_state_dict(sd)
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are refused: nothing in the product routes through PyTorch-CPU arithmetic or the oracle."""
+    query, pool = aecf_amd.create_fusion_pool(64, 3)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        pool(query.expand(4, -1, -1), torch.randn(4, 3, 64))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        pool.curriculum_masking(torch.softmax(torch.randn(4, 3), -1))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        pool.curriculum_masking.entropy_loss(torch.rand(4))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        aecf_amd.multimodal_attention_pool(torch.randn(2, 1, 8), torch.randn(2, 3, 8))
+    src = open(os.path.join(ROOT, "aecf_amd", "layer.py")).read() + open(os.path.join(ROOT, "aecf_amd", "_lib.py")).read()
+    assert "import oracle" not in src and "from oracle" not in src
+    assert "nn.functional.multi_head_attention_forward" not in src and "scaled_dot_product_attention(" not in src.replace(
+        "_scaled_dot_product_attention(", "")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libaecf_hip.so")
+    with pytest.raises(RuntimeError, match="HIP library not found"):
+        _lib.load()

@@ -47,6 +47,8 @@ def test_mask_stage_bit_exact(name):
     assert torch.allclose(r["entropy"], t(g["entropy"]), rtol=2e-6, atol=1e-7)
     assert torch.equal(r["mask_rate"], t(g["mask_rate"]))
     assert torch.equal(r["target_entropy"], t(g["target_entropy"]))
+    dw = O.curriculum_mask_train_backward(t(g["weights"]), r["mask"], t(g["d_masked"]))
+    assert rel_err(dw, g["d_weights"]) < 1e-5
 
 
 def _close(a, b):

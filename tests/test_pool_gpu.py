@@ -1,0 +1,348 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the aecf_amd host mirror) against
+ (a) the golden vectors captured from the reference and (b) the CPU oracle on the same inputs.
+
+Tolerances (BASELINE.json north_star): fp32 1e-5 relative, bf16 1e-3 relative; masks bit-exact for given
+uniforms.  "relative" = max|got - want| / max|want| over the tensor (tests/helpers.rel_err).
+bf16: the target is fp32 math on the bf16-representable inputs (fixture protocol G6); tensors the
+path STORES in bf16 (y, dx) carry an extra half-ulp of output rounding (2^-9 relative to the element), so
+they are checked against 1e-3 + one bf16 rounding; float32 outputs (weights, parameter gradients) at 1e-3
+flat ... see the per-assert comments.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import ROOT, g2_names, g3_names, load_json, load_npz, rel_err, t
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-5
+BF16_TOL = 1e-3
+BF16_STORE_TOL = 1e-3 + 2.0 ** -8     # + one bf16 output rounding of the largest element
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _record(name, **kw):
+    path = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "parity_errors.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test=name, **{k: float(v) for k, v in kw.items()})) + "\n")
+
+
+def _build_pool(g, dtype, curriculum=None):
+    import aecf_amd
+    dev = _dev()
+    E, H = int(g["E"]), int(g["H"])
+    pool = aecf_amd.MultimodalAttentionPool(E, num_heads=H, curriculum_masking=curriculum)
+    with torch.no_grad():
+        pool.attention.in_proj_weight.copy_(t(g["w_in"]))
+        pool.attention.in_proj_bias.copy_(t(g["b_in"]))
+        pool.attention.out_proj.weight.copy_(t(g["w_out"]))
+        pool.attention.out_proj.bias.copy_(t(g["b_out"]))
+    return pool.to(device=dev, dtype=dtype)
+
+
+def _run_g2(name, dtype):
+    g = load_npz(name)
+    dev = _dev()
+    B = int(g["B"])
+    pool = _build_pool(g, dtype)
+    pool.train()
+    x = t(g["x"]).to(dev, dtype).requires_grad_(True)
+    q0 = t(g["query"]).to(dev, dtype).requires_grad_(True)
+    kpm = torch.from_numpy(g["key_padding_mask"]).to(dev) if "key_padding_mask" in g else None
+    y, info = pool(q0.expand(B, -1, -1), x, key_padding_mask=kpm, return_info=True)
+    wbar = info["attention_weights"]
+    loss = (y.float() * t(g["dy"]).to(dev)).sum() + (wbar.float() * t(g["dwbar"]).to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    a = pool.attention
+    got = dict(y=y, wbar=wbar, dx=x.grad, dquery=q0.grad, dw_in=a.in_proj_weight.grad, db_in=a.in_proj_bias.grad,
+               dw_out=a.out_proj.weight.grad, db_out=a.out_proj.bias.grad)
+    return g, {k: v.detach().float().cpu() for k, v in got.items()}
+
+
+FP32_CASES = [n for n in g2_names() if "bf16" not in n and "perq" not in n]
+BF16_CASES = [n for n in g2_names() if "bf16" in n]
+
+
+@pytest.mark.parametrize("name", FP32_CASES + BF16_CASES)
+def test_pool_fp32_matches_reference(name):
+    """fp32 path against the reference's own outputs (forward and autograd backward)."""
+    g, got = _run_g2(name, torch.float32)
+    errs = {k: rel_err(got[k], g[k]) for k in got}
+    _record("fp32:" + name, **errs)
+    for k, e in errs.items():
+        assert e < FP32_TOL, (name, k, e)
+
+
+@pytest.mark.parametrize("name", BF16_CASES)
+def test_pool_bf16_matches_fp32_math(name):
+    """bf16 path against fp32 math of the reference on the same bf16-representable inputs."""
+    g, got = _run_g2(name, torch.bfloat16)
+    errs = {k: rel_err(got[k], g[k]) for k in got}
+    _record("bf16:" + name, **errs)
+    # head-averaged weights come out of the kernel in float32 (rounded to bf16 by the host mirror)
+    assert errs["wbar"] < BF16_STORE_TOL, (name, errs)
+    for k in ("y", "dx", "dquery", "dw_in", "db_in", "dw_out", "db_out"):
+        assert errs[k] < BF16_STORE_TOL, (name, k, errs[k])
+
+
+def test_pool_bf16_float32_statistics():
+    """The float32 side outputs of the bf16 kernel (weights, probabilities) meet 1e-3 without output rounding."""
+    import aecf_amd
+    from aecf_amd import _lib
+    from aecf_amd.layer import _PoolFunction
+    g = load_npz("g2_mha_bf16_e128h4m3.npz")
+    dev = _dev()
+    B, H = int(g["B"]), int(g["H"])
+    bf = torch.bfloat16
+    y, attn_w, _, _, _ = _PoolFunction.apply(
+        t(g["x"]).to(dev, bf), t(g["query"]).to(dev, bf), t(g["w_in"]).to(dev, bf), t(g["b_in"]).to(dev, bf),
+        t(g["w_out"]).to(dev, bf), t(g["b_out"]).to(dev, bf), None, None, H, 0, 1, 0.15, 0.7, 1e-8)
+    e = rel_err(attn_w.cpu().reshape(B, 1, -1), g["wbar"])
+    _record("bf16:float32_wbar", wbar=e)
+    assert e < 1e-5      # scores use a hi/lo bf16 split of the folded key matrix: float32-accurate
+
+
+@pytest.mark.parametrize("name", g3_names())
+def test_mask_stage_bit_exact(name):
+    """Stand-alone CurriculumMasking kernel on the reference's own weights and uniforms:
+    mask pattern bit-exact, masked weights / entropy within float32 rounding, backward matches autograd."""
+    import aecf_amd
+    from aecf_amd import layer
+    g = load_npz(name)
+    dev = _dev()
+    mod = aecf_amd.CurriculumMasking(base_mask_prob=float(g["p_base"]), min_active=int(g["min_active"])).to(dev)
+    mod.train()
+    w = t(g["weights"]).to(dev).requires_grad_(True)
+    layer._uniforms_override = t(g["uniforms"])
+    masked, info = mod(w)
+    (masked * t(g["d_masked"]).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal((masked != 0).cpu(), torch.from_numpy(g["nonzero"])), "mask pattern differs"
+    assert torch.equal(info["mask_rate"].cpu(), t(g["mask_rate"]))
+    assert torch.allclose(masked.detach().cpu(), t(g["masked"]), rtol=1e-6, atol=1e-8)
+    assert torch.allclose(info["entropy"].cpu(), t(g["entropy"]), rtol=1e-5, atol=1e-6)
+    assert torch.equal(info["target_entropy"].cpu(), t(g["target_entropy"]))
+    assert info["mask_rate"].dtype == torch.float32 and not info["entropy"].requires_grad
+    assert mod._last_seq_len == int(g["last_seq_len"])
+    assert rel_err(w.grad.cpu(), g["d_weights"]) < 1e-5
+
+
+def test_mask_edges():
+    import aecf_amd
+    from aecf_amd import layer
+    g = load_npz("g4_edges.npz")
+    dev = _dev()
+    keys = sorted({k.split(".")[0] for k in g if k.endswith(".U")})
+    for key in keys:
+        p, tau, k = g[f"{key}.kw"]
+        mod = aecf_amd.CurriculumMasking(float(p), float(tau), int(k)).to(dev)
+        mod.train()
+        layer._uniforms_override = t(g[f"{key}.U"])
+        masked, info = mod(t(g[f"{key}.w"]).to(dev))
+        layer._uniforms_override = None
+        nn = lambda a: torch.nan_to_num(torch.as_tensor(a), nan=123.0)
+        assert torch.allclose(nn(masked.cpu()), nn(t(g[f"{key}.masked"])), rtol=1e-6, atol=1e-8), key
+        assert torch.allclose(nn(info["entropy"].cpu()), nn(t(g[f"{key}.entropy"])), rtol=1e-5, atol=1e-6), key
+        assert torch.equal(nn(info["mask_rate"].cpu()), nn(t(g[f"{key}.mask_rate"]))), key
+        assert torch.equal(nn(info["target_entropy"].cpu()), nn(t(g[f"{key}.target"]))), key
+    # eval mode: weights returned unchanged (same object), entropy attached, no target key
+    mod = aecf_amd.CurriculumMasking().to(dev)
+    mod.eval()
+    w = t(g["eval.w"]).to(dev)
+    masked, info = mod(w)
+    assert masked is w
+    assert sorted(info.keys()) == ["entropy", "mask_rate"]
+    assert torch.allclose(info["entropy"].cpu(), t(g["eval.entropy"]), rtol=1e-5, atol=1e-6)
+    assert torch.equal(info["mask_rate"].cpu(), t(g["eval.mask_rate"]))
+    w2 = t(g["evalgrad.w"]).to(dev).requires_grad_(True)
+    _, info2 = mod(w2)
+    assert info2["entropy"].requires_grad
+    (info2["entropy"] * t(g["evalgrad.dent"]).to(dev)).sum().backward()
+    assert rel_err(w2.grad.cpu(), g["evalgrad.dw"]) < 1e-5
+
+
+def test_entropy_loss():
+    import aecf_amd
+    dev = _dev()
+    for c in load_json("g5_entropy_loss.json"):
+        mod = aecf_amd.CurriculumMasking().to(dev)
+        mod._last_seq_len = c["last_seq_len"]
+        e = torch.tensor([float(v) for v in c["entropy"]], device=dev, requires_grad=True)
+        loss = mod.entropy_loss(e)
+        loss.backward()
+        assert loss.dim() == 0
+        assert abs(float(loss) - c["loss"]) <= 2e-6 * max(1.0, abs(c["loss"])), c
+        assert torch.allclose(e.grad.cpu(), torch.tensor(c["grad"]), rtol=1e-5, atol=1e-7), c
+
+
+def test_functional_api():
+    import aecf_amd
+    g = load_npz("g7_functional.npz")
+    dev = _dev()
+    q, k, v = (t(g[n]).to(dev).requires_grad_(True) for n in ("q", "k", "v"))
+    out = aecf_amd.multimodal_attention_pool(q, k, v)
+    (out * t(g["do"]).to(dev)).sum().backward()
+    assert rel_err(out.detach().cpu(), g["fast"]) < FP32_TOL
+    assert rel_err(q.grad.cpu(), g["dq"]) < FP32_TOL
+    assert rel_err(k.grad.cpu(), g["dk"]) < FP32_TOL
+    assert rel_err(v.grad.cpu(), g["dv"]) < FP32_TOL
+    assert rel_err(aecf_amd.multimodal_attention_pool(q.detach(), k.detach()).cpu(), g["fast_kv"]) < FP32_TOL
+    # bf16 fast path against fp32 math
+    ob = aecf_amd.multimodal_attention_pool(q.detach().bfloat16(), k.detach().bfloat16(), v.detach().bfloat16())
+    assert rel_err(ob.float().cpu(), g["fast"]) < 2e-2
+
+
+def test_g1_plumbing_readme_pattern():
+    """create_fusion_pool(512, 2) under the reference's seed: same parameters (RNG order), same outputs, same info
+    contract in train and eval mode."""
+    import aecf_amd
+    from aecf_amd import layer
+    g = load_npz("g1_plumbing.npz")
+    dev = _dev()
+    torch.manual_seed(int(g["seed_init"]))
+    query, pool = aecf_amd.create_fusion_pool(embed_dim=512, num_modalities=2)
+    assert np.allclose(query.detach().numpy()[0, 0, :8], g["query_head"])
+    assert np.allclose(pool.attention.in_proj_weight.detach().numpy()[0, :8], g["w_in_head"])
+    assert np.allclose(pool.attention.out_proj.weight.detach().numpy()[0, :8], g["w_out_head"])
+    assert list(pool.state_dict().keys()) == list(g["sd_keys"])
+    pool = pool.to(dev)
+    query = query.detach().to(dev).requires_grad_(True)
+    x = torch.randn(32, 2, 512, generator=torch.Generator().manual_seed(int(g["seed_x"]))).to(dev)
+    pool.train()
+    layer._uniforms_override = t(g["uniforms"])
+    out, info = pool(query.expand(32, -1, -1), x, return_info=True)
+    assert out.shape == (32, 1, 512)
+    assert sorted(info.keys()) == list(g["train_keys"])
+    assert rel_err(out.detach().cpu(), g["out"]) < FP32_TOL
+    assert rel_err(info["attention_weights"].detach().cpu(), g["attention_weights"]) < FP32_TOL
+    assert rel_err(info["entropy"].cpu(), g["entropy"]) < FP32_TOL
+    assert torch.equal(info["mask_rate"].cpu(), t(g["mask_rate"]))
+    assert str(info["mask_rate"].dtype) == str(g["mask_rate_dtype"])
+    assert torch.equal(info["target_entropy"].cpu(), t(g["target_entropy"]))
+    assert torch.equal((info["masked_attention_weights"] != 0).cpu(), t(g["masked_attention_weights"]) != 0)
+    assert rel_err(info["masked_attention_weights"].cpu(), g["masked_attention_weights"]) < FP32_TOL
+    assert info["attention_weights"].requires_grad and not info["entropy"].requires_grad
+    assert not info["masked_attention_weights"].requires_grad
+    assert info["entropy"].shape == (32, 1) and info["attention_weights"].shape == (32, 1, 2)
+    pool.eval()
+    out_e, info_e = pool(query.expand(32, -1, -1), x, return_info=True)
+    assert sorted(info_e.keys()) == list(g["eval_keys"])
+    assert rel_err(out_e.detach().cpu(), g["out_eval"]) < FP32_TOL
+    assert rel_err(info_e["entropy"].detach().cpu(), g["entropy_eval"]) < FP32_TOL
+    assert info_e["entropy"].requires_grad
+    assert pool.extra_repr() == str(g["repr_pool"]) and pool.curriculum_masking.extra_repr() == str(g["repr_mask"])
+
+
+def test_options_seq_first_eval_no_curriculum():
+    import aecf_amd
+    g = load_npz("g8_options.npz")
+    dev = _dev()
+
+    def mk(prefix, **kw):
+        pool = aecf_amd.MultimodalAttentionPool(64, num_heads=4, **kw)
+        with torch.no_grad():
+            pool.attention.in_proj_weight.copy_(t(g[prefix + ".w_in"]))
+            pool.attention.in_proj_bias.copy_(t(g[prefix + ".b_in"]))
+            pool.attention.out_proj.weight.copy_(t(g[prefix + ".w_out"]))
+            pool.attention.out_proj.bias.copy_(t(g[prefix + ".b_out"]))
+        return pool.to(dev)
+
+    # batch_first=False: I/O transposed, weights stay [N, tgt, M]
+    pool = mk("sf", batch_first=False).eval()
+    x = t(g["sf.x"]).to(dev)
+    q = t(g["sf.q"]).to(dev)
+    y, info = pool(q.expand(1, x.shape[1], -1), x, return_info=True)
+    assert y.shape == tuple(g["sf.y"].shape)
+    assert rel_err(y.cpu(), g["sf.y"]) < FP32_TOL
+    assert rel_err(info["attention_weights"].cpu(), g["sf.w"]) < FP32_TOL
+    # eval mode with a curriculum module attached
+    pool2 = mk("ev", curriculum_masking=aecf_amd.CurriculumMasking(0.2)).eval()
+    x = t(g["ev.x"]).to(dev)
+    q = t(g["ev.q"]).to(dev)
+    y2, info2 = pool2(q.expand(x.shape[0], -1, -1), x, return_info=True)
+    assert sorted(info2.keys()) == list(g["ev.keys"])
+    assert rel_err(y2.cpu(), g["ev.y"]) < FP32_TOL
+    assert rel_err(info2["entropy"].cpu(), g["ev.entropy"]) < FP32_TOL
+    assert rel_err(info2["masked_attention_weights"].cpu(), g["ev.masked"]) < FP32_TOL
+    assert torch.equal(info2["mask_rate"].cpu(), t(g["ev.mask_rate"]))
+    # no curriculum: plain output without return_info, only attention_weights with it; use_checkpoint is a no-op
+    pool3 = mk("nc").train()
+    y3 = pool3(q.expand(x.shape[0], -1, -1), x)
+    y3b, info3 = pool3(q.expand(x.shape[0], -1, -1), x, return_info=True, use_checkpoint=True)
+    assert sorted(info3.keys()) == list(g["nc.keys"])
+    assert rel_err(y3.cpu(), g["nc.y"]) < FP32_TOL and torch.equal(y3, y3b)
+
+
+def test_eval_entropy_gradient_reaches_parameters():
+    """eval mode keeps info['entropy'] attached (ref :150-156): its gradient must flow through the weights
+    into x and the parameters exactly as the oracle's closed form says."""
+    import aecf_amd
+    from oracle import aecf_oracle as O
+    g = load_npz("g2_mha_e64h4m3.npz")
+    dev = _dev()
+    B, H = int(g["B"]), int(g["H"])
+    pool = _build_pool(g, torch.float32, curriculum=aecf_amd.CurriculumMasking(0.2)).eval()
+    x = t(g["x"]).to(dev).requires_grad_(True)
+    q0 = t(g["query"]).to(dev)
+    _, info = pool(q0.expand(B, -1, -1), x, return_info=True)
+    gH = torch.randn(B, 1, generator=torch.Generator().manual_seed(3))
+    (info["entropy"] * gH.to(dev)).sum().backward()
+    xc, qc = t(g["x"]), t(g["query"]).expand(B, -1, -1)
+    f = O.mha_forward(qc, xc, xc, t(g["w_in"]), t(g["b_in"]), t(g["w_out"]), t(g["b_out"]), H)
+    dwbar = O.entropy_rows_backward(f["wbar"], gH)
+    b = O.mha_backward(qc, xc, xc, t(g["w_in"]), t(g["b_in"]), t(g["w_out"]), H, f, torch.zeros_like(f["y"]), dwbar)
+    assert rel_err(x.grad.cpu(), b["dkey"] + b["dvalue"]) < 2e-5
+    assert rel_err(pool.attention.in_proj_weight.grad.cpu(), b["dw_in"]) < 2e-5
+
+
+def test_fused_mask_equals_oracle_on_kernel_weights():
+    """Mask contract: the oracle masking fed the kernel's OWN float32 head-averaged weights
+    and the same uniforms yields the identical mask pattern and masked weights."""
+    from aecf_amd.layer import _PoolFunction
+    from oracle import aecf_oracle as O
+    dev = _dev()
+    gen = torch.Generator().manual_seed(11)
+    B, M, E, H = 8192, 3, 128, 4
+    x = torch.randn(B, M, E, generator=gen) * torch.tensor([1.0, 2.0, 3.0]).view(1, 3, 1)
+    q = torch.randn(E, generator=gen) * 0.3
+    w_in = torch.randn(3 * E, E, generator=gen) / math.sqrt(E)
+    w_out = torch.randn(E, E, generator=gen) / math.sqrt(E)
+    U = torch.rand(B, M, generator=gen)
+    for dtype in (torch.float32, torch.bfloat16):
+        for p_base, k in ((0.15, 1), (1.0, 1), (0.7, 2)):
+            y, attn_w, masked, ent, rate = _PoolFunction.apply(
+                x.to(dev, dtype), q.to(dev, dtype), w_in.to(dev, dtype), None, w_out.to(dev, dtype), None, None,
+                U.to(dev), H, 1, k, p_base, 0.7, 1e-8)
+            r = O.curriculum_mask_train(attn_w.cpu(), U, p_base, 0.7, k)
+            assert torch.equal((masked != 0).cpu(), r["masked"] != 0)
+            assert torch.equal(rate.cpu(), r["mask_rate"])
+            assert torch.allclose(masked.cpu(), r["masked"], rtol=1e-6, atol=1e-8)
+            assert torch.allclose(ent.cpu(), r["entropy"], rtol=1e-5, atol=1e-6)
+            assert float((attn_w.sum(-1) - 1).abs().max()) < 1e-5
+
+
+def test_unsupported_configurations_fail_loudly():
+    import aecf_amd
+    dev = _dev()
+    pool = aecf_amd.MultimodalAttentionPool(64, num_heads=2).to(dev)
+    x = torch.randn(4, 3, 64, device=dev)
+    with pytest.raises(NotImplementedError):
+        pool(torch.randn(4, 1, 64, device=dev), x)                    # per-sample queries
+    with pytest.raises(NotImplementedError):
+        pool(torch.randn(1, 1, 64, device=dev).expand(4, -1, -1), x, x.clone())   # value is not key
+    with pytest.raises(NotImplementedError):
+        pool(torch.randn(1, 1, 64, device=dev).expand(4, -1, -1), x, attn_mask=torch.zeros(1, 3, device=dev))
+    pool8 = aecf_amd.MultimodalAttentionPool(64, num_heads=8).to(dev)           # head_dim 8
+    with pytest.raises(RuntimeError, match="not supported"):
+        pool8(torch.randn(1, 1, 64, device=dev).expand(4, -1, -1), x)
