@@ -1,0 +1,144 @@
+"""Data-parallel plumbing for the fusion path: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference is single-process (no collective anywhere in it), so this layer has no reference
+counterpart; it is what BASELINE.json's north_star asks for around the fused kernels:
+
+* samples are independent in the forward/backward kernels -> each rank runs a contiguous batch shard,
+  parameters and the fusion query are replicated;
+* the only exchange steps are (1) ONE all-reduce of all parameter gradients per step, flat-bucketed so
+  the 4E^2+5E values travel as a single collective (a few MB: latency-bound on xGMI, so one big
+  message, not one per tensor), (2) an all-gather of fused embeddings for cross-batch contrastive
+  negatives whose backward is a reduce-scatter of the gradient, (3) scalar means of the logged statistics.
+* mask RNG: every rank slices the SAME global uniform tensor, so N-rank masks equal 1-rank masks bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_bounds(global_batch: int, rank: int, world: int):
+    """Contiguous, balanced shard [lo, hi) of the batch for this rank (first ranks take the remainder)."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    lo, hi = shard_bounds(t.shape[0], rank, world)
+    return t[lo:hi]
+
+
+def global_uniforms(global_batch: int, tgt_len: int, modalities: int, seed: int, device) -> torch.Tensor:
+    """The [B_global, tgt, M] float32 uniforms every rank agrees on (same seed -> same tensor); a rank
+    consumes ``shard_batch(u, rank, world)``.  B_global*M floats: negligible next to the activations."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    return torch.rand(global_batch, tgt_len, modalities, dtype=torch.float32, device=device, generator=g)
+
+
+class FlatGradBucket:
+    """All parameter gradients of the replicated model in ONE flat buffer.
+
+    ``p.grad`` of every parameter is a view into ``self.flat`` (per dtype), so backward accumulates
+    straight into the bucket and ``all_reduce()`` is a single in-place collective -- no per-tensor copies.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradBucket needs at least one parameter that requires grad")
+        self.buffers = {}
+        by_dtype = {}
+        for p in self.params:
+            by_dtype.setdefault((p.dtype, p.device), []).append(p)
+        for (dtype, device), ps in by_dtype.items():
+            flat = torch.zeros(sum(p.numel() for p in ps), dtype=dtype, device=device)
+            off = 0
+            for p in ps:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.buffers[(dtype, device)] = flat
+
+    @property
+    def numel(self) -> int:
+        return sum(b.numel() for b in self.buffers.values())
+
+    def zero(self) -> None:
+        for b in self.buffers.values():
+            b.zero_()
+
+    def all_reduce(self, group=None, average: bool = True, async_op: bool = False):
+        """Sum (and optionally average) the bucket across ranks, in place."""
+        _, world = world_info(group)
+        if world == 1:
+            return []
+        works = []
+        for b in self.buffers.values():
+            if average:
+                b.div_(world)           # pre-divide: the sum of bf16 buckets then stays in range
+            works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+        return works
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """z_local [b, d] -> z_all [sum b, d] (rank order); backward: each rank keeps the gradient rows of its own
+    shard summed over ranks (reduce-scatter; all-reduce + slice where the backend has no reduce_scatter)."""
+
+    @staticmethod
+    def forward(ctx, z, group):
+        rank, world = world_info(group)
+        ctx.group, ctx.rank, ctx.world = group, rank, world
+        if world == 1:
+            ctx.sizes = [z.shape[0]]
+            return z.clone()
+        n = torch.tensor([z.shape[0]], device=z.device, dtype=torch.int64)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n, group=group)
+        ctx.sizes = [int(s.item()) for s in sizes]
+        zc = z.contiguous()
+        if len(set(ctx.sizes)) == 1:
+            out = torch.empty(world * zc.shape[0], *zc.shape[1:], dtype=z.dtype, device=z.device)
+            dist.all_gather_into_tensor(out, zc, group=group)
+            return out
+        parts = [torch.empty(s, *zc.shape[1:], dtype=z.dtype, device=z.device) for s in ctx.sizes]
+        dist.all_gather(parts, zc, group=group)
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, dz_all):
+        if ctx.world == 1:
+            return dz_all, None
+        lo = sum(ctx.sizes[:ctx.rank])
+        hi = lo + ctx.sizes[ctx.rank]
+        dz_all = dz_all.contiguous()
+        even = len(set(ctx.sizes)) == 1
+        if even and dist.get_backend(ctx.group) == "nccl":
+            out = torch.empty(ctx.sizes[ctx.rank], *dz_all.shape[1:], dtype=dz_all.dtype, device=dz_all.device)
+            dist.reduce_scatter_tensor(out, dz_all, op=dist.ReduceOp.SUM, group=ctx.group)
+            return out, None
+        dist.all_reduce(dz_all, op=dist.ReduceOp.SUM, group=ctx.group)
+        return dz_all[lo:hi].clone(), None
+
+
+def all_gather_rows(z: torch.Tensor, group=None) -> torch.Tensor:
+    """Autograd-aware all-gather of fused embeddings (cross-batch contrastive negatives)."""
+    return _AllGatherRows.apply(z, group)
+
+
+def all_reduce_mean_scalar(v: torch.Tensor, weight: float = 1.0, group=None) -> torch.Tensor:
+    """Weighted mean of a scalar statistic over ranks (weight = local sample count)."""
+    _, world = world_info(group)
+    if world == 1:
+        return v.detach().clone()
+    buf = torch.stack([v.detach().float() * weight, torch.tensor(float(weight), device=v.device)])
+    dist.all_reduce(buf, group=group)
+    return buf[0] / buf[1]

@@ -51,19 +51,21 @@ def make_inputs(cfg, device):
     return pool, query, x, dy
 
 
-def step(pool, query, x, dy, params, world):
+def step(pool, query, x, dy, params, bucket):
+    """One pass of the hot path over one resident batch: forward (+ entropy_loss) + backward (+ the one
+    gradient all-reduce when data-parallel)."""
     B = x.shape[0]
     out, info = pool(query.expand(B, -1, -1), x, return_info=True)
     ent_loss = pool.curriculum_masking.entropy_loss(info["entropy"])
-    for p in params:
-        p.grad = None
     x.grad = None
+    if bucket is None:
+        for p in params:
+            p.grad = None
+    else:
+        bucket.zero()                       # parameter gradients accumulate straight into the flat bucket
     torch.autograd.backward([out], [dy])
-    if world > 1:
-        import torch.distributed as dist
-        flat = torch.cat([p.grad.reshape(-1).float() for p in params])
-        dist.all_reduce(flat)
-        flat.div_(world)
+    if bucket is not None:
+        bucket.all_reduce(average=True)     # ONE RCCL all-reduce of 4E^2+5E values
     return out, ent_loss
 
 
@@ -74,6 +76,10 @@ class StageTimer:
         from aecf_amd import _lib
         self._lib = _lib
         self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventCreate.restype = ctypes.c_int
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventElapsedTime.restype = ctypes.c_int
         self.nf, self.nb = _lib.AECF_FWD_STAGES, _lib.AECF_BWD_STAGES
         self.fwd = (ctypes.c_void_p * (self.nf + 1))()
         self.bwd = (ctypes.c_void_p * (self.nb + 1))()
@@ -181,6 +187,10 @@ def main():
     B, M, E, H, dtype, p = cfg
     pool, query, x, dy = make_inputs(cfg, device)
     params = [query] + list(pool.parameters())
+    bucket = None
+    if world > 1:
+        from aecf_amd.dp import FlatGradBucket
+        bucket = FlatGradBucket(params)
 
     def barrier():
         if world > 1:
@@ -189,11 +199,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(pool, query, x, dy, params, world)
+        step(pool, query, x, dy, params, bucket)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(pool, query, x, dy, params, world)
+        step(pool, query, x, dy, params, bucket)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -209,7 +219,7 @@ def main():
         st = StageTimer()
         for _ in range(min(args.steps, 20)):
             st.arm()
-            step(pool, query, x, dy, params, 1)
+            step(pool, query, x, dy, params, None)
             st.disarm()
             torch.cuda.synchronize()
             st.collect()
