@@ -1,0 +1,208 @@
+// gemm_nt: C[R,N] = A(R,K) W[N,K]^T + bias -- LDS-tiled MFMA GEMM (gfx950).
+//
+// Block = 256 threads = 2x2 waves; block tile 128 rows x 128 cols, wave tile 64 x 64 (4x4 MFMA 16x16 tiles,
+// 64 accumulator VGPRs).  K advances 128 bytes per tile (64 bf16 / 32 f32).  Both operands are staged
+// through LDS from registers: the global loads of tile t+1 are issued before the MFMAs of tile t and written
+// to LDS after the next barrier, so their latency hides under the matrix work (one LDS buffer, two barriers
+// per tile).  Rows of the weight matrix come from L2 (<= 2 MB, shared by every block); the activation tile
+// is read once per column block.
+//
+// POOLED (the V projection of the fusion pool): the A operand of output head h is
+//     pooled_h[b,:] = sum_m probs[b,h,m] * x[b,m,:]
+// formed in registers from the M staged x tiles while the fragments are read (fp32 FMA, one rounding to the
+// MFMA input type), so V is projected once per sample instead of once per (sample, modality).
+//
+// bf16 output leaves through LDS as full 256-byte rows; f32 output is stored from the accumulator layout.
+#include "aecf_kernels.h"
+#include "aecf_tile.h"
+
+namespace aecf {
+
+template <typename T, int M_, bool POOLED>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
+    using X = Tr<T>;
+    typedef typename X::elem elem;
+    typedef typename X::frag frag;
+    constexpr int NA = POOLED ? M_ : 1;          // A-side LDS tiles (one per modality when pooling)
+    constexpr int TILE = 128 * TILE_ROW_BYTES;   // 16 KB
+    constexpr int BK = TileK<T>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsA = smem;
+    char* ldsB = smem + NA * TILE;
+
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    const int wr = w >> 1, wc = w & 1;
+    const int64_t r0 = (int64_t)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 128;
+    const int rows_valid = (p.R - r0) >= 128 ? 128 : (int)(p.R - r0);
+    const int cols_valid = (p.N - n0) >= 128 ? 128 : (p.N - n0);
+    const int K = p.K;
+    const int nkt = K / BK;
+
+    const char* a_src = reinterpret_cast<const char*>(p.a) + r0 * p.lda * X::BYTES;
+    const char* w_src = reinterpret_cast<const char*>(p.w) + (int64_t)n0 * K * X::BYTES;
+    const int64_t lda_bytes = p.lda * X::BYTES;
+    const int64_t ldw_bytes = (int64_t)K * X::BYTES;
+
+    // wave-level column bookkeeping
+    const int nw0 = n0 + 64 * wc;
+    int nct = (p.N - nw0) >= 64 ? 4 : ((p.N - nw0) > 0 ? (p.N - nw0) / 16 : 0);
+    int head[4];
+    float pr[4][4][M_];
+    if (POOLED) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            int h = (nw0 + 16 * ct) / p.hd;
+            head[ct] = h < p.H ? h : p.H - 1;
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            int64_t row = r0 + 64 * wr + 16 * rt + r16;
+            if (row >= p.R) row = p.R - 1;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int m = 0; m < M_; ++m) pr[rt][ct][m] = p.probs[(row * p.H + head[ct]) * M_ + m];
+        }
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    DirectStage<128, 256> sa[NA], sb;
+#pragma unroll
+    for (int m = 0; m < NA; ++m) sa[m].load(a_src + (int64_t)m * K * X::BYTES, lda_bytes, rows_valid);
+    sb.load(w_src, ldw_bytes, cols_valid);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                       // everyone finished reading the previous tile
+#pragma unroll
+        for (int m = 0; m < NA; ++m) sa[m].store(ldsA + m * TILE);
+        sb.store(ldsB);
+        __syncthreads();
+        if (kt + 1 < nkt) {                    // next tile's loads fly during the MFMAs below
+            const int64_t koff = (int64_t)(kt + 1) * TILE_ROW_BYTES;
+#pragma unroll
+            for (int m = 0; m < NA; ++m) sa[m].load(a_src + (int64_t)m * K * X::BYTES + koff, lda_bytes, rows_valid);
+            sb.load(w_src + koff, ldw_bytes, cols_valid);
+        }
+        if (!POOLED) {
+            tile_mma<T, 4, 4>(acc, ldsA, 64 * wr, ldsB, 64 * wc);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                frag bf[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) bf[ct] = lds_frag<T>(ldsB, 64 * wc + 16 * ct + r16, 4 * ks + lg);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    float xm[M_][X::EPL];
+#pragma unroll
+                    for (int m = 0; m < M_; ++m)
+                        X::unpack(lds_frag<T>(ldsA + m * TILE, 64 * wr + 16 * rt + r16, 4 * ks + lg), xm[m]);
+                    frag pa = X::zero();
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        if (ct < nct) {
+                            if (ct == 0 || head[ct] != head[ct - 1]) {
+                                float pv[X::EPL];
+#pragma unroll
+                                for (int j = 0; j < X::EPL; ++j) {
+                                    float v = pr[rt][ct][0] * xm[0][j];
+#pragma unroll
+                                    for (int m = 1; m < M_; ++m) v = fmaf(pr[rt][ct][m], xm[m][j], v);
+                                    pv[j] = v;
+                                }
+                                pa = X::pack(pv);
+                            }
+                            acc[rt][ct] = X::mma(pa, bf[ct], acc[rt][ct]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    const elem* bias = reinterpret_cast<const elem*>(p.bias);
+    float bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int n = nw0 + 16 * ct + r16;
+        bv[ct] = (bias && ct < nct) ? X::to_f32(bias[n]) : 0.f;
+    }
+    if (X::BYTES == 2) {
+        // accumulators -> LDS as a [128][128] bf16 image (256-byte rows), then full-row 16-byte stores
+        __syncthreads();
+        char* cl = smem;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                // lane r16 holds column c for rows 4*lg + 0..3; pair columns (c, c+1) across lanes r16 ^ 1
+                float v0 = acc[rt][ct][0] + bv[ct], v1 = acc[rt][ct][1] + bv[ct];
+                float v2 = acc[rt][ct][2] + bv[ct], v3 = acc[rt][ct][3] + bv[ct];
+                const bool odd = r16 & 1;
+                // even lane keeps rows 0,1 and receives the neighbour's rows 0,1; odd lane keeps rows 2,3
+                const float send0 = odd ? v0 : v2, send1 = odd ? v1 : v3;
+                const float got0 = __shfl_xor(send0, 1, 64), got1 = __shfl_xor(send1, 1, 64);
+                const int col = 64 * wc + 16 * ct + (r16 & ~1);
+                const int rowb = 64 * wr + 16 * rt + 4 * lg + (odd ? 2 : 0);
+                const unsigned int d0 = odd ? pack_bf16x2(got0, v2) : pack_bf16x2(v0, got0);
+                const unsigned int d1 = odd ? pack_bf16x2(got1, v3) : pack_bf16x2(v1, got1);
+                *reinterpret_cast<unsigned int*>(cl + (rowb + 0) * 256 + col * 2) = d0;
+                *reinterpret_cast<unsigned int*>(cl + (rowb + 1) * 256 + col * 2) = d1;
+            }
+        __syncthreads();
+        char* c = reinterpret_cast<char*>(p.c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = threadIdx.x + 256 * i;          // 2048 chunks of 16 B: row = ch / 16, chunk = ch % 16
+            const int row = ch >> 4, cc = ch & 15;
+            if (row < rows_valid && cc * 8 < cols_valid)
+                *reinterpret_cast<u32x4*>(c + ((r0 + row) * p.N + n0) * 2 + cc * 16) =
+                    *reinterpret_cast<const u32x4*>(cl + row * 256 + cc * 16);
+        }
+    } else {
+        elem* c = reinterpret_cast<elem*>(p.c);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            if (ct < nct) {
+                const int n = nw0 + 16 * ct + r16;
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = r0 + 64 * wr + 16 * rt + 4 * lg + r;
+                        if (row < p.R) c[row * p.N + n] = X::from_f32(acc[rt][ct][r] + bv[ct]);
+                    }
+            }
+        }
+    }
+}
+
+template <typename T, int M_, bool POOLED>
+static void launch_one(const GemmNtArgs& a, hipStream_t s) {
+    constexpr int NA = POOLED ? M_ : 1;
+    const size_t smem = (size_t)(NA + 1) * 128 * TILE_ROW_BYTES;
+    dim3 grid((unsigned)((a.R + 127) / 128), (a.N + 127) / 128), block(256);
+    auto kern = gemm_nt_kernel<T, M_, POOLED>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a);
+}
+
+void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s) {
+    if (!a.pooled) {
+        if (dtype == 0) launch_one<BF16, 1, false>(a, s); else launch_one<F32, 1, false>(a, s);
+        return;
+    }
+    AECF_DISPATCH_M(a.M, {
+        if (dtype == 0) launch_one<BF16, M_, true>(a, s); else launch_one<F32, M_, true>(a, s);
+    });
+}
+
+}  // namespace aecf

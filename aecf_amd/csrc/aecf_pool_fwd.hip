@@ -166,113 +166,6 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(GateArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// gemm_nt: C[R,N] = A(R,K) W[N,K]^T + bias.  Block = 4 waves; block tile 64 rows x 256 cols; each wave
-// owns 64 x 64 (4 x 4 MFMA tiles, 64 accumulator registers).  Operand fragments are loaded straight
-// from global memory (weights are L2-resident; x/o stream once per column block).
-// POOLED: the A fragment of column tile ct is the probability-weighted sum over modalities of the x
-// fragments, formed in registers (fp32 FMA, rounded once to the MFMA input type).
-template <typename T, int M_, bool POOLED>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
-    using X = Tr<T>;
-    typedef typename X::elem elem;
-    typedef typename X::frag frag;
-    constexpr int RT = 4, CT = 4;
-    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
-    const int n0 = blockIdx.y * 256 + wave_id() * 64;
-    if (n0 >= p.N) return;
-    const int nct = (p.N - n0) >= 64 ? CT : (p.N - n0) / 16;
-    const int K = p.K;
-
-    const elem* wbase = reinterpret_cast<const elem*>(p.w) + (int64_t)(n0 + r16) * K + X::EPL * lg;
-    const elem* abase[RT];
-    int64_t rowc[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        int64_t row = r0 + 16 * rt + r16;
-        rowc[rt] = row < p.R ? row : p.R - 1;
-        abase[rt] = reinterpret_cast<const elem*>(p.a) + rowc[rt] * p.lda + X::EPL * lg;
-    }
-    // probabilities for the pooled operand: pr[rt][ct][m] = probs[row][head(ct)][m]
-    float pr[RT][CT][M_];
-    int head[CT];
-    if (POOLED) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            int h = (n0 + 16 * ct) / p.hd;
-            head[ct] = h < p.H ? h : p.H - 1;
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int m = 0; m < M_; ++m) pr[rt][ct][m] = p.probs[(rowc[rt] * p.H + head[ct]) * M_ + m];
-    }
-
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int k0 = 0; k0 < K; k0 += X::KSTEP) {
-        frag wf[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-            wf[ct] = (ct < nct) ? X::load(wbase + (int64_t)(16 * ct) * K + k0) : X::zero();
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if (!POOLED) {
-                frag af = X::load(abase[rt] + k0);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    if (ct < nct) acc[rt][ct] = X::mma(af, wf[ct], acc[rt][ct]);
-            } else {
-                float xm[M_][X::EPL];
-#pragma unroll
-                for (int m = 0; m < M_; ++m) X::unpack(X::load(abase[rt] + (int64_t)m * K + k0), xm[m]);
-                frag pa = X::zero();
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    if (ct < nct) {
-                        if (ct == 0 || head[ct] != head[ct - 1]) {
-                            float pv[X::EPL];
-#pragma unroll
-                            for (int j = 0; j < X::EPL; ++j) {
-                                float v = pr[rt][ct][0] * xm[0][j];
-#pragma unroll
-                                for (int m = 1; m < M_; ++m) v = fmaf(pr[rt][ct][m], xm[m][j], v);
-                                pv[j] = v;
-                            }
-                            pa = X::pack(pv);
-                        }
-                        acc[rt][ct] = X::mma(pa, wf[ct], acc[rt][ct]);
-                    }
-                }
-            }
-        }
-    }
-
-    elem* c = reinterpret_cast<elem*>(p.c);
-    const elem* bias = reinterpret_cast<const elem*>(p.bias);
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        if (ct < nct) {
-            const int n = n0 + 16 * ct + r16;
-            const float bv = bias ? X::to_f32(bias[n]) : 0.f;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = r0 + 16 * rt + 4 * lg + r;
-                    if (row < p.R) c[row * p.N + n] = X::from_f32(acc[rt][ct][r] + bv);
-                }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 #define LAUNCH_CHECKED(...) __VA_ARGS__
 
 void launch_prep_qs(int dtype, const void* w_in, const void* b_in, const void* query, float* qs, int E, float scale,
@@ -311,23 +204,6 @@ void launch_gate_fwd(int dtype, const GateArgs& a, hipStream_t s) {
             gate_fwd_kernel<BF16, M_><<<grid, block, 0, s>>>(a);
         else
             gate_fwd_kernel<F32, M_><<<grid, block, 0, s>>>(a);
-    });
-}
-
-void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s) {
-    dim3 grid((unsigned)((a.R + 63) / 64), (a.N + 255) / 256), block(256);
-    if (!a.pooled) {
-        if (dtype == 0)
-            gemm_nt_kernel<BF16, 1, false><<<grid, block, 0, s>>>(a);
-        else
-            gemm_nt_kernel<F32, 1, false><<<grid, block, 0, s>>>(a);
-        return;
-    }
-    AECF_DISPATCH_M(a.M, {
-        if (dtype == 0)
-            gemm_nt_kernel<BF16, M_, true><<<grid, block, 0, s>>>(a);
-        else
-            gemm_nt_kernel<F32, M_, true><<<grid, block, 0, s>>>(a);
     });
 }
 

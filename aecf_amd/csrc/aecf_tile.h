@@ -1,0 +1,73 @@
+// LDS tile engine shared by the MFMA kernels (gfx950).
+//
+// An LDS tile is ROWS x 128 bytes: one row = the K-slice of one matrix row (64 bf16 or 32 f32 = two MFMA
+// K-steps).  The 8 16-byte chunks of a row are XOR-swizzled with (row >> 1) & 7 so that the ds_read_b128 of
+// a fragment (16 consecutive rows, same logical chunk) touches 16 distinct 16-byte slots of the 256-byte
+// bank row: conflict-free.  Tiles are filled from registers (coalesced 16-byte global loads issued one
+// K-tile ahead, written after the barrier), so the staging can also transform the data on the way in
+// (transpose for batch-reduction GEMMs, probability-weighted pooling over modalities).
+#pragma once
+#include "aecf_common.h"
+
+namespace aecf {
+
+constexpr int TILE_ROW_BYTES = 128;
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * TILE_ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T> struct TileK;   // elements of K per 128-byte LDS row
+template <> struct TileK<BF16> { static constexpr int value = 64; };
+template <> struct TileK<F32> { static constexpr int value = 32; };
+
+// Cooperative register staging of a ROWS x 128 B tile from a row-major source, NT threads.
+// chunk c = tid + NT*i  ->  row = c >> 3, 16-byte chunk = c & 7: 8 consecutive lanes read one full 128-B line.
+template <int ROWS, int NT>
+struct DirectStage {
+    static constexpr int N = ROWS * 8 / NT;
+    u32x4 r[N];
+    // src: byte pointer to element (row0, k-byte offset) of the source; ld_bytes: row pitch; rows_valid: rows that exist
+    __device__ __forceinline__ void load(const char* __restrict__ src, int64_t ld_bytes, int rows_valid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = threadIdx.x + NT * i;
+            const int row = c >> 3, ch = c & 7;
+            r[i] = row < rows_valid ? *reinterpret_cast<const u32x4*>(src + row * ld_bytes + ch * 16)
+                                    : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = threadIdx.x + NT * i;
+            *reinterpret_cast<u32x4*>(lds + lds_off(c >> 3, c & 7)) = r[i];
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::frag lds_frag(const char* lds, int row, int chunk) {
+    return *reinterpret_cast<const typename Tr<T>::frag*>(lds + lds_off(row, chunk));
+}
+
+// acc[rt][ct] += A(rows rowA0 + 16 rt ..) * B(rows rowB0 + 16 ct ..)^T over the two K-steps of the tile
+template <typename T, int RT, int CT>
+__device__ __forceinline__ void tile_mma(f32x4 (&acc)[RT][CT], const char* ldsA, int rowA0, const char* ldsB, int rowB0) {
+    using X = Tr<T>;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        typename X::frag a[RT], b[CT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = lds_frag<T>(ldsA, rowA0 + 16 * rt + r16, 4 * ks + lg);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) b[ct] = lds_frag<T>(ldsB, rowB0 + 16 * ct + r16, 4 * ks + lg);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = X::mma(a[rt], b[ct], acc[rt][ct]);
+    }
+}
+
+}  // namespace aecf
