@@ -233,17 +233,13 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     launch_gemm_tn(d->dtype, t1, s);
     mark(ev, 3, s);
 
-    BwdDaArgs da;
-    da.x = a->x; da.dobuf = dobuf; da.wvt = wvt; da.probs = a->saved_probs; da.d_attn_w = a->d_attn_w;
-    da.d_entropy = a->d_entropy; da.attn_w = a->attn_w; da.dsbuf = dsbuf; da.B = B; da.M = M; da.E = E; da.H = H;
-    da.hd = hd; da.log_M = (float)log((double)M);
-    launch_bwd_da(d->dtype, da, s);
+    BwdGArgs g2;
+    g2.x = a->x; g2.dobuf = dobuf; g2.wvt = wvt; g2.probs = a->saved_probs; g2.d_attn_w = a->d_attn_w;
+    g2.d_entropy = a->d_entropy; g2.attn_w = a->attn_w; g2.dsbuf = dsbuf; g2.a_f32 = a_f32; g2.dx = a->dx;
+    g2.B = B; g2.M = M; g2.E = E; g2.H = H; g2.hd = hd; g2.log_M = (float)log((double)M);
+    launch_bwd_g(d->dtype, g2, false, s);
     mark(ev, 4, s);
-
-    BwdDxArgs dx;
-    dx.dobuf = dobuf; dx.wvt = wvt; dx.probs = a->saved_probs; dx.dsbuf = dsbuf; dx.a_f32 = a_f32; dx.dx = a->dx;
-    dx.B = B; dx.M = M; dx.E = E; dx.H = H; dx.hd = hd;
-    launch_bwd_dx(d->dtype, dx, s);
+    launch_bwd_g(d->dtype, g2, true, s);
     mark(ev, 5, s);
 
     // dW_v = do^T pooled, db_v = colsum(do), u = ds^T x

@@ -55,34 +55,25 @@ struct GemmNtArgs {
 void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
 
 // ---------------- backward ----------------
-// pass 1: da[b,h,m] = (W_v,h^T do_h[b]) . x[b,m]  ->  ds = softmax-backward  -> dsbuf [B,H,M]
-struct BwdDaArgs {
-    const void* x;        // [B,M,E]
-    const void* dobuf;    // [B,E] dtype  (dy W_o)
-    const void* wvt;      // [E(k), E(j)] dtype = W_v^T
-    const float* probs;   // [B,H,M]
+// g_h[b] = W_v,h^T do_h[b] kernels (aecf_bwd_g.hip):
+//   dx == false: da[b,h,m] = g_h[b] . x[b,m] -> ds = softmax-backward(da + dwbar/H) -> dsbuf [B,H,M]
+//   dx == true : dx[b,m,k] = sum_h probs[b,h,m] g_h[b][k] + sum_h ds[b,h,m] A[h][k]
+struct BwdGArgs {
+    const void* x;           // [B,M,E]
+    const void* dobuf;       // [B,E] dtype  (dy W_o)
+    const void* wvt;         // [E(k), E(j)] dtype = W_v^T
+    const float* probs;      // [B,H,M]
     const float* d_attn_w;   // [B,M] or null
     const float* d_entropy;  // [B] or null (eval mode)
     const float* attn_w;     // [B,M] (with d_entropy)
-    float* dsbuf;         // [B,H,M]
+    float* dsbuf;            // [B,H,M]  (written by the da pass, read by the dx pass)
+    const float* a_f32;      // [HPAD,E]
+    void* dx;                // [B,M,E] dtype
     int64_t B;
     int M, E, H, hd;
     float log_M;
 };
-void launch_bwd_da(int dtype, const BwdDaArgs& a, hipStream_t s);
-
-// pass 2: dx[b,m,k] = sum_h probs[b,h,m] (W_v,h^T do_h[b])[k] + sum_h ds[b,h,m] A[h][k]
-struct BwdDxArgs {
-    const void* dobuf;
-    const void* wvt;
-    const float* probs;
-    const float* dsbuf;
-    const float* a_f32;   // [HPAD,E]
-    void* dx;             // [B,M,E] dtype
-    int64_t B;
-    int M, E, H, hd;
-};
-void launch_bwd_dx(int dtype, const BwdDxArgs& a, hipStream_t s);
+void launch_bwd_g(int dtype, const BwdGArgs& a, bool dx, hipStream_t s);
 
 // out[split][j][k] = sum_{b in split} lhs[b][j] * rhs(b,k)        (f32 partial slabs, deterministic)
 //   pooled == 0: rhs(b,k) = rhs[b*E + k]

@@ -17,157 +17,6 @@
 
 namespace aecf {
 
-// -(log w + 1) where the entropy clamp of ref :126-128 is inactive (eval-mode entropy keeps its graph)
-template <int M_>
-__device__ __forceinline__ void entropy_grad_row(const float* w, float dent, float log_M, float* out) {
-    float h = 0.f;
-#pragma unroll
-    for (int m = 0; m < M_; ++m) h -= xlogx(w[m]);
-    const bool live = (h >= 0.f) && (h <= log_M);
-#pragma unroll
-    for (int m = 0; m < M_; ++m) out[m] = live ? -(logf(w[m]) + 1.0f) * dent : 0.f;
-}
-
-// one 16(E rows) x 16(samples) tile of g_h^T: rows k0..k0+15 of W_v^T against do_h of 16 samples
-template <typename T>
-__device__ __forceinline__ f32x4 g_tile(const typename Tr<T>::elem* __restrict__ wvt_row,   // &wvt[(k0+r16)*E + h*hd + EPL*lg]
-                                        const typename Tr<T>::elem* __restrict__ do_row,    // &do[b*E + h*hd + EPL*lg]
-                                        int hd) {
-    using X = Tr<T>;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < hd; j0 += X::KSTEP) acc = X::mma(X::load(wvt_row + j0), X::load(do_row + j0), acc);
-    return acc;
-}
-
-// block = 64 * NW threads (NW = ceil(E/128) waves, wave w owns E rows [128w, 128w+128)); 16 samples per block
-template <typename T, int M_>
-__global__ __launch_bounds__(512) void bwd_da_kernel(BwdDaArgs p) {
-    using X = Tr<T>;
-    typedef typename X::elem elem;
-    __shared__ float red[8][16][M_];
-    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
-    const int nw = blockDim.x >> 6;
-    const int E = p.E, H = p.H, hd = p.hd;
-    const int64_t b0 = (int64_t)blockIdx.x * 16;
-    const int64_t bs = b0 + r16;
-    const int64_t bc = bs < p.B ? bs : p.B - 1;
-    const int kbeg = w * 128;
-    const int nrt = (E - kbeg) >= 128 ? 8 : (E - kbeg) / 16;
-    const elem* x = reinterpret_cast<const elem*>(p.x) + bc * M_ * (int64_t)E;
-    const elem* dorow = reinterpret_cast<const elem*>(p.dobuf) + bc * (int64_t)E + X::EPL * lg;
-    const elem* wvt = reinterpret_cast<const elem*>(p.wvt);
-
-    // upstream gradient on the head-averaged weights (train: d_attn_w; eval adds the entropy path)
-    float dwb[M_];
-#pragma unroll
-    for (int m = 0; m < M_; ++m) dwb[m] = p.d_attn_w ? p.d_attn_w[bc * M_ + m] : 0.f;
-    if (p.d_entropy) {
-        float wv[M_], ge[M_];
-#pragma unroll
-        for (int m = 0; m < M_; ++m) wv[m] = p.attn_w[bc * M_ + m];
-        entropy_grad_row<M_>(wv, p.d_entropy[bc], p.log_M, ge);
-#pragma unroll
-        for (int m = 0; m < M_; ++m) dwb[m] += ge[m];
-    }
-    const float invH = 1.0f / (float)H;
-
-    for (int h = 0; h < H; ++h) {
-        float da[M_];
-#pragma unroll
-        for (int m = 0; m < M_; ++m) da[m] = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
-            if (rt < nrt) {
-                const int k0 = kbeg + 16 * rt;
-                f32x4 g = g_tile<T>(wvt + (int64_t)(k0 + r16) * E + h * hd + X::EPL * lg, dorow + h * hd, hd);
-#pragma unroll
-                for (int m = 0; m < M_; ++m) {
-                    float xv[4];
-                    X::load4(x + (int64_t)m * E + k0 + 4 * lg, xv);
-                    da[m] += g[0] * xv[0] + g[1] * xv[1] + g[2] * xv[2] + g[3] * xv[3];
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < M_; ++m) {
-            da[m] = reduce_lg(da[m]);
-            if (lg == 0) red[w][r16][m] = da[m];
-        }
-        __syncthreads();
-        if (w == 0 && lg == 0) {
-            float pm[M_], dp[M_];
-            float dot = 0.f;
-#pragma unroll
-            for (int m = 0; m < M_; ++m) {
-                float t = 0.f;
-                for (int ww = 0; ww < nw; ++ww) t += red[ww][r16][m];
-                pm[m] = p.probs[(bc * H + h) * M_ + m];
-                dp[m] = t + dwb[m] * invH;
-                dot += pm[m] * dp[m];
-            }
-            if (bs < p.B) {
-#pragma unroll
-                for (int m = 0; m < M_; ++m) p.dsbuf[(bs * H + h) * M_ + m] = pm[m] * (dp[m] - dot);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// grid (ceil(B/16), ceil(E / (64*RTW))); block 256 = 4 waves, wave owns RTW row tiles (16*RTW E positions)
-template <typename T, int M_, int RTW>
-__global__ __launch_bounds__(256) void bwd_dx_kernel(BwdDxArgs p) {
-    using X = Tr<T>;
-    typedef typename X::elem elem;
-    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
-    const int E = p.E, H = p.H, hd = p.hd;
-    const int kbeg = (blockIdx.y * 4 + wave_id()) * 16 * RTW;
-    if (kbeg >= E) return;
-    const int nrt = (E - kbeg) >= 16 * RTW ? RTW : (E - kbeg) / 16;
-    const int64_t bs = (int64_t)blockIdx.x * 16 + r16;
-    const int64_t bc = bs < p.B ? bs : p.B - 1;
-    const elem* dorow = reinterpret_cast<const elem*>(p.dobuf) + bc * (int64_t)E + X::EPL * lg;
-    const elem* wvt = reinterpret_cast<const elem*>(p.wvt);
-
-    f32x4 acc[M_][RTW];
-#pragma unroll
-    for (int m = 0; m < M_; ++m)
-#pragma unroll
-        for (int rt = 0; rt < RTW; ++rt) acc[m][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int h = 0; h < H; ++h) {
-        float pm[M_], dsm[M_];
-#pragma unroll
-        for (int m = 0; m < M_; ++m) {
-            pm[m] = p.probs[(bc * H + h) * M_ + m];
-            dsm[m] = p.dsbuf[(bc * H + h) * M_ + m];
-        }
-#pragma unroll
-        for (int rt = 0; rt < RTW; ++rt) {
-            if (rt < nrt) {
-                const int k0 = kbeg + 16 * rt;
-                f32x4 g = g_tile<T>(wvt + (int64_t)(k0 + r16) * E + h * hd + X::EPL * lg, dorow + h * hd, hd);
-                const f32x4 av = *reinterpret_cast<const f32x4*>(p.a_f32 + (int64_t)h * E + k0 + 4 * lg);
-#pragma unroll
-                for (int m = 0; m < M_; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[m][rt][r] += pm[m] * g[r] + dsm[m] * av[r];
-            }
-        }
-    }
-    if (bs < p.B) {
-        elem* dx = reinterpret_cast<elem*>(p.dx) + bs * M_ * (int64_t)E;
-#pragma unroll
-        for (int m = 0; m < M_; ++m)
-#pragma unroll
-            for (int rt = 0; rt < RTW; ++rt)
-                if (rt < nrt) {
-                    float v[4] = {acc[m][rt][0], acc[m][rt][1], acc[m][rt][2], acc[m][rt][3]};
-                    X::store4(dx + (int64_t)m * E + kbeg + 16 * rt + 4 * lg, v);
-                }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // gemm_tn: out[j][k] = sum_b lhs[b][j] rhs[b][k] -- the reduction runs over the batch, which is the
 // slow axis of both row-major operands.  Each lane loads an NR(batch rows) x 4(features) block with
@@ -436,28 +285,6 @@ __global__ __launch_bounds__(256) void fin_dquery_kernel(FinalizeArgs p) {  // g
 }
 
 // ------------------------------------------------------------------------------------------
-void launch_bwd_da(int dtype, const BwdDaArgs& a, hipStream_t s) {
-    const int nw = (a.E + 127) / 128;
-    dim3 grid((unsigned)((a.B + 15) / 16)), block(64 * nw);
-    AECF_DISPATCH_M(a.M, {
-        if (dtype == 0)
-            bwd_da_kernel<BF16, M_><<<grid, block, 0, s>>>(a);
-        else
-            bwd_da_kernel<F32, M_><<<grid, block, 0, s>>>(a);
-    });
-}
-
-void launch_bwd_dx(int dtype, const BwdDxArgs& a, hipStream_t s) {
-    AECF_DISPATCH_M(a.M, {
-        constexpr int RTW = (M_ <= 4) ? 8 : 4;
-        dim3 grid((unsigned)((a.B + 15) / 16), (a.E + 64 * RTW - 1) / (64 * RTW)), block(256);
-        if (dtype == 0)
-            bwd_dx_kernel<BF16, M_, RTW><<<grid, block, 0, s>>>(a);
-        else
-            bwd_dx_kernel<F32, M_, RTW><<<grid, block, 0, s>>>(a);
-    });
-}
-
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s) {
     dim3 grid((a.E + 127) / 128, (a.E + 127) / 128, a.splits), block(256);
     if (!a.pooled) {

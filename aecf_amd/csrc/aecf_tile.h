@@ -1,11 +1,14 @@
 // LDS tile engine shared by the MFMA kernels (gfx950).
 //
 // An LDS tile is ROWS x 128 bytes: one row = the K-slice of one matrix row (64 bf16 or 32 f32 = two MFMA
-// K-steps).  The 8 16-byte chunks of a row are XOR-swizzled with (row >> 1) & 7 so that the ds_read_b128 of
-// a fragment (16 consecutive rows, same logical chunk) touches 16 distinct 16-byte slots of the 256-byte
-// bank row: conflict-free.  Tiles are filled from registers (coalesced 16-byte global loads issued one
-// K-tile ahead, written after the barrier), so the staging can also transform the data on the way in
-// (transpose for batch-reduction GEMMs, probability-weighted pooling over modalities).
+// K-steps).  The 8 16-byte chunks of a row are XOR-swizzled with s(row) = ((row >> 1) ^ (row >> 4)) & 7:
+//   * fragment read (ds_read_b128, 16 consecutive rows, same logical chunk): (row & 1, chunk ^ s) covers the
+//     16 distinct 16-byte slots of the 256-byte bank row -> conflict-free;
+//   * direct staging write (8 consecutive lanes = one row, chunks 0..7): 8 distinct slots;
+//   * transposed staging write (8 consecutive lanes = rows 8*f + i, one chunk): s takes 8 distinct values.
+// Tiles are filled from registers (coalesced 16-byte global loads issued one tile ahead, written after the
+// barrier), so the staging can also transform the data on the way in (transpose for batch-reduction GEMMs,
+// probability-weighted pooling over modalities).
 #pragma once
 #include "aecf_common.h"
 
@@ -14,7 +17,7 @@ namespace aecf {
 constexpr int TILE_ROW_BYTES = 128;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-    return row * TILE_ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+    return row * TILE_ROW_BYTES + ((chunk ^ (((row >> 1) ^ (row >> 4)) & 7)) << 4);
 }
 
 template <typename T> struct TileK;   // elements of K per 128-byte LDS row
@@ -25,23 +28,27 @@ template <> struct TileK<F32> { static constexpr int value = 32; };
 // chunk c = tid + NT*i  ->  row = c >> 3, 16-byte chunk = c & 7: 8 consecutive lanes read one full 128-B line.
 template <int ROWS, int NT>
 struct DirectStage {
-    static constexpr int N = ROWS * 8 / NT;
+    static constexpr int N = (ROWS * 8 + NT - 1) / NT;
     u32x4 r[N];
-    // src: byte pointer to element (row0, k-byte offset) of the source; ld_bytes: row pitch; rows_valid: rows that exist
-    __device__ __forceinline__ void load(const char* __restrict__ src, int64_t ld_bytes, int rows_valid) {
+    // src: byte pointer to element (row0, k-byte offset) of the source; ld_bytes: row pitch; rows_valid: rows that
+    // exist; chunks_valid: 16-byte chunks of the K-slice that exist (the rest is zero-filled)
+    __device__ __forceinline__ void load(const char* __restrict__ src, int64_t ld_bytes, int rows_valid,
+                                         int chunks_valid = 8) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int c = threadIdx.x + NT * i;
             const int row = c >> 3, ch = c & 7;
-            r[i] = row < rows_valid ? *reinterpret_cast<const u32x4*>(src + row * ld_bytes + ch * 16)
-                                    : u32x4{0u, 0u, 0u, 0u};
+            r[i] = (row < rows_valid && ch < chunks_valid)
+                       ? *reinterpret_cast<const u32x4*>(src + row * ld_bytes + ch * 16)
+                       : u32x4{0u, 0u, 0u, 0u};
         }
     }
     __device__ __forceinline__ void store(char* lds) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int c = threadIdx.x + NT * i;
-            *reinterpret_cast<u32x4*>(lds + lds_off(c >> 3, c & 7)) = r[i];
+            if (ROWS * 8 % NT == 0 || c < ROWS * 8)
+                *reinterpret_cast<u32x4*>(lds + lds_off(c >> 3, c & 7)) = r[i];
         }
     }
 };
