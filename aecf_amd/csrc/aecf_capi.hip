@@ -31,7 +31,7 @@ FwdWs fwd_layout(const aecf_pool_desc* d) {
 }
 
 struct BwdWs {
-    size_t qs, a_f32, a_hi, a_lo, wvt, wot, dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, total;
+    size_t qs, a_f32, a_hi, a_lo, wvt, wot, dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, dq_part, total;
     int splits;
     int64_t rows_per_split;
 };
@@ -65,6 +65,7 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     w.u_slab = off; off = align_up(off + (size_t)S * HPAD * E * 4);
     w.u = off;      off = align_up(off + HPAD * E * 4);
     w.dqp = off;    off = align_up(off + E * 4);
+    w.dq_part = off; off = align_up(off + (E / 64) * E * 4);
     w.total = off;
     return w;
 }
@@ -250,14 +251,18 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     launch_gemm_tn(d->dtype, t2, s);
     mark(ev, 6, s);
 
-    launch_reduce_slabs((const float*)(ws + L.slab_o), a->dw_out, (int64_t)E * E, L.splits, s);
-    launch_reduce_slabs((const float*)(ws + L.cs_o), a->db_out, E, L.splits, s);
-    launch_reduce_slabs((const float*)(ws + L.slab_v), a->dw_in + (size_t)2 * E * E, (int64_t)E * E, L.splits, s);
-    launch_reduce_slabs((const float*)(ws + L.cs_v), a->db_in + 2 * E, E, L.splits, s);
-    launch_reduce_slabs((const float*)(ws + L.u_slab), u, (int64_t)HPAD * E, L.splits, s);
+    ReduceSegs rs;
+    rs.splits = L.splits;
+    rs.src[0] = (const float*)(ws + L.slab_o); rs.dst[0] = a->dw_out;                    rs.n[0] = (int64_t)E * E;
+    rs.src[1] = (const float*)(ws + L.cs_o);   rs.dst[1] = a->db_out;                    rs.n[1] = E;
+    rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = a->dw_in + (size_t)2 * E * E; rs.n[2] = (int64_t)E * E;
+    rs.src[3] = (const float*)(ws + L.cs_v);   rs.dst[3] = a->db_in + 2 * E;             rs.n[3] = E;
+    rs.src[4] = (const float*)(ws + L.u_slab); rs.dst[4] = u;                            rs.n[4] = (int64_t)HPAD * E;
+    launch_reduce_segments(rs, s);
 
     FinalizeArgs f;
-    f.w_in = a->w_in; f.query = a->query; f.qs = qs; f.u = u; f.dqp = (float*)(ws + L.dqp); f.dw_in = a->dw_in;
+    f.w_in = a->w_in; f.query = a->query; f.qs = qs; f.u = u; f.dqp = (float*)(ws + L.dqp);
+    f.dq_part = (float*)(ws + L.dq_part); f.dw_in = a->dw_in;
     f.db_in = a->db_in; f.dquery = a->dquery; f.E = E; f.H = H; f.hd = hd; f.scale = scale;
     launch_finalize(d->dtype, f, s);
     mark(ev, 7, s);

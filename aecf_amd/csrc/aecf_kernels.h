@@ -96,8 +96,15 @@ struct GemmTnArgs {
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
 
-// dst[i] = sum_s src[s][i]    (n elements, S slabs)
-void launch_reduce_slabs(const float* src, float* dst, int64_t n, int S, hipStream_t s);
+// dst[g][i] = sum_s src[g][s*n[g] + i] for each of N segments, one launch
+struct ReduceSegs {
+    static constexpr int N = 5;
+    const float* src[N];
+    float* dst[N];
+    int64_t n[N];
+    int splits;
+};
+void launch_reduce_segments(const ReduceSegs& r, hipStream_t s);
 
 // dW_k[j][k] = qs[j] u[h(j)][k];  dqp[j] = scale * sum_k W_k[j][k] u[h(j)][k]
 // dW_q[j][k] = dqp[j] q[k]; db_q = dqp; db_k = 0; dquery[k] = sum_j dqp[j] W_q[j][k]
@@ -107,6 +114,7 @@ struct FinalizeArgs {
     const float* qs;
     const float* u;       // [HPAD,E] reduced
     float* dqp;           // [E] scratch
+    float* dq_part;       // [E/64, E] scratch (dquery partials per j-block)
     float* dw_in;         // [3E,E]
     float* db_in;         // [3E]
     float* dquery;        // [E]
