@@ -28,7 +28,7 @@ constexpr int G_WAVES = 8;
 constexpr int G_THREADS = 64 * G_WAVES;
 
 template <typename T, int M_, bool DX>
-__global__ __launch_bounds__(G_THREADS) void bwd_g_kernel(BwdGArgs p) {
+__global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
     constexpr int BK = TileK<T>::value;

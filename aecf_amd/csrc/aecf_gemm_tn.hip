@@ -1,15 +1,16 @@
 // gemm_tn: out[j][k] = sum_b lhs[b][j] * rhs(b,k) -- batch-reduction GEMM for the parameter gradients (gfx950).
 //
 // The reduction index (the batch) is the SLOW axis of both row-major operands, so neither can feed an MFMA
-// fragment directly.  Each thread loads an NB x NB block (NB batch rows x NB features; 16-byte coalesced
-// loads, 8x8 for bf16 / 4x4 for f32), transposes it in registers and writes it to an LDS tile whose rows are
+// fragment directly.  Each thread loads an NR x NF block (4 batch rows x 8 bf16 / 4 f32 features; 16-byte
+// coalesced loads), transposes it in registers and writes it to an LDS tile whose rows are
 // FEATURES and whose 128-byte K-slice is the batch (aecf_tile.h); from there both operands are ordinary
 // fragment reads.  The staging pass is also where the work that differs from a plain GEMM happens:
 //   * column sums of lhs (the bias gradients) fall out of the blocks already in registers;
 //   * POOLED: rhs(b,k) = sum_m probs[b, head(j), m] * x[b,m,k] is formed per head slot while staging
 //     (the V-projection gradient dW_v,h = do_h^T pooled_h), fp32 FMA, one rounding to the MFMA input type;
-//   * POOLED, j-tile 0 only: u[h][k] = sum_{b,m} ds[b,h,m] x[b,m,k] (the key-side gradient) by one extra
-//     MFMA chain per modality against a raw transposed x tile.
+//   * POOLED: one extra row of blocks (blockIdx.y == number of j tiles) computes the key-side gradient
+//     u[h][k] = sum_{b,m} ds[b,h,m] x[b,m,k] from raw transposed x tiles (A operand = ds, built in registers
+//     as a bf16 hi/lo pair so the tiny ds values keep ~16 bits).
 // Output: float32 partial slabs per batch split (deterministic; reduced by reduce_slabs).
 //
 // Block = 256 threads.  Block tile BJ x 128 with BJ = 128 (64 when head_dim % 32 != 0); the wave tile is chosen so
@@ -57,7 +58,7 @@ template <> struct TBlk<F32> {
     }
 };
 
-template <typename T, int M_, bool POOLED, int WJ>
+template <typename T, int M_, bool POOLED, int WJ, int MAXS>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     using X = Tr<T>;
     typedef typename X::frag frag;
@@ -68,14 +69,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     constexpr int CT = (WJ == 64) ? 4 : 8;
     constexpr int FG = 128 / NF;                         // feature groups per 128 features
     constexpr int BG = BBT / NR;                         // batch groups per step
-    constexpr int NBLK_R = FG * BG;                      // register blocks in a [128 features][BBT batch] tile
-    constexpr int NBLK_L = (BJ / NF) * BG;
-    constexpr int MAXS = 4;                              // head slots per block
+    constexpr int NBLK = FG * BG;                        // register blocks per [128 features][BBT batch] tile (256)
+    // MAXS: head slots per block (compile time: 1, 2 or 4)
+    constexpr int PLN = (BBT * MAXS * M_ + 255) / 256;   // probability values staged per thread per step
+    static_assert(NBLK == 256, "one register block per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int E = p.E, H = p.H;
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
-    const int j0 = blockIdx.y * BJ, k0 = blockIdx.x * 128;
+
+    constexpr bool u_block = false;                               // (u has its own kernel below)
+    const int j0 = u_block ? 0 : blockIdx.y * BJ, k0 = blockIdx.x * 128;
     const int split = blockIdx.z;
     const int64_t rbeg = (int64_t)split * p.rows_per_split;
     const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
@@ -85,20 +89,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     const int h_first = POOLED ? j0 / p.hd : 0;
     const int h_last = POOLED ? (j0 + jrows - 1) / p.hd : 0;
     const int nslots = h_last - h_first + 1;
-    const bool do_u = POOLED && blockIdx.y == 0;
 
-    // LDS carve
+    // LDS carve: L tile | R tiles (head slots, or raw x_m tiles in the u block) | probs | colsum scratch
     char* ldsL = smem;
-    char* ldsR = ldsL + BJ * TILE_ROW_BYTES;                                   // nslots tiles of [128][128 B]
-    char* ldsX = ldsR + (POOLED ? MAXS : 1) * 128 * TILE_ROW_BYTES;            // raw x tile for u (pooled)
-    float* pl = reinterpret_cast<float*>(ldsX + (POOLED ? 128 * TILE_ROW_BYTES : 0));   // probs [BBT][MAXS][M]
-    float* csl = pl + (POOLED ? BBT * MAXS * M_ : 0);                          // colsum scratch [BG][BJ]
+    char* ldsR = ldsL + BJ * TILE_ROW_BYTES;
+    float* pl = reinterpret_cast<float*>(ldsR + (POOLED ? MAXS : 1) * 128 * TILE_ROW_BYTES);   // [BBT][MAXS][M]
+    float* csl = pl + (POOLED ? BBT * MAXS * M_ : 0);                                         // [BG][BJ]
 
-    // wave tile
+    // wave tile of the j x k output
     const int wj = (WJ == 64) ? (w >> 1) : w;
     const int j0w = WJ * wj;
     const int k0w = (WJ == 64) ? 64 * (w & 1) : 0;
-    const bool wave_on = j0w < jrows && k0w < kcols;
+    const bool wave_on = !u_block && j0w < jrows && k0w < kcols;
     const int wslot = POOLED ? ((j0 + (j0w < jrows ? j0w : 0)) / p.hd - h_first) : 0;
     const int nct = wave_on ? ((kcols - k0w) >= 16 * CT ? CT : (kcols - k0w) / 16) : 0;
 
@@ -107,8 +109,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     for (int a = 0; a < RT; ++a)
 #pragma unroll
         for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 uacc[2];
-    uacc[0] = uacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     float cs[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) cs[f] = 0.f;
@@ -118,167 +118,118 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     const int64_t ldl = (int64_t)E * X::BYTES;
     const int64_t ldr = (int64_t)(POOLED ? M_ : 1) * E * X::BYTES;
 
-    // this thread's blocks: q = tid (+256): fg = q % FG (feature group), bg = q / FG (batch group = LDS chunk)
-    constexpr int NQL = (NBLK_L + 255) / 256, NQR = (NBLK_R + 255) / 256;
-    TBlk<T> Lb[NQL];
-    TBlk<T> Rb[NQR][POOLED ? M_ : 1];
+    // this thread's register block: feature group fg, batch group bg (both tiles use the same indices)
+    const int fgl = threadIdx.x % (BJ / NF), bgl = threadIdx.x / (BJ / NF);     // lhs tile (BJ features)
+    const int fgr = threadIdx.x % FG, bgr = threadIdx.x / FG;                   // rhs tile (128 features)
+    const bool l_on = !u_block && bgl < BG && NF * fgl < jrows;
+    const bool r_on = NF * fgr < kcols;
+    TBlk<T> Lb;
+    TBlk<T> Rb[POOLED ? M_ : 1];
+    float plr[POOLED ? PLN : 1];
 
     auto load_step = [&](int64_t base) {
 #pragma unroll
-        for (int i = 0; i < NQL; ++i) {
-            const int q = threadIdx.x + 256 * i;
-            const int fg = q % (BJ / NF), bg = q / (BJ / NF);
-            const bool on = q < NBLK_L && NF * fg < jrows;
-#pragma unroll
-            for (int t = 0; t < NR; ++t) {
-                const int64_t bb = base + NR * bg + t;
-                if (on && bb < rend) Lb[i].load_row(t, lhs + bb * ldl + (int64_t)(j0 + NF * fg) * X::BYTES);
-                else Lb[i].zero_row(t);
-            }
+        for (int t = 0; t < NR; ++t) {
+            const int64_t bb = base + NR * bgl + t;
+            if (l_on && bb < rend) Lb.load_row(t, lhs + bb * ldl + (int64_t)(j0 + NF * fgl) * X::BYTES);
+            else Lb.zero_row(t);
         }
 #pragma unroll
-        for (int i = 0; i < NQR; ++i) {
-            const int q = threadIdx.x + 256 * i;
-            const int fg = q % FG, bg = q / FG;
-            const bool on = q < NBLK_R && NF * fg < kcols;
+        for (int m = 0; m < (POOLED ? M_ : 1); ++m)
 #pragma unroll
-            for (int m = 0; m < (POOLED ? M_ : 1); ++m)
+            for (int t = 0; t < NR; ++t) {
+                const int64_t bb = base + NR * bgr + t;
+                if (r_on && bb < rend) Rb[m].load_row(t, rhs + bb * ldr + ((int64_t)m * E + k0 + NF * fgr) * X::BYTES);
+                else Rb[m].zero_row(t);
+            }
+        if (POOLED && !u_block) {
 #pragma unroll
-                for (int t = 0; t < NR; ++t) {
-                    const int64_t bb = base + NR * bg + t;
-                    if (on && bb < rend)
-                        Rb[i][m].load_row(t, rhs + bb * ldr + ((int64_t)m * E + k0 + NF * fg) * X::BYTES);
-                    else Rb[i][m].zero_row(t);
-                }
+            for (int i = 0; i < PLN; ++i) {
+                const int idx = threadIdx.x + 256 * i;          // (t, s, m) with MAXS slots per row
+                const int t = idx / (MAXS * M_), rem = idx - t * (MAXS * M_);
+                const int s = rem / M_, m = rem - s * M_;
+                const int64_t bb = base + t;
+                plr[i] = (idx < BBT * MAXS * M_ && s < nslots && bb < rend)
+                             ? p.probs[(bb * H + h_first + s) * M_ + m] : 0.f;
+            }
         }
     };
 
     load_step(rbeg);
     for (int64_t base = rbeg; base < rend; base += BBT) {
         __syncthreads();                                  // previous step's MFMAs are done with the tiles
-        if (POOLED) {                                     // probabilities of this step's batch rows, per head slot
-            for (int i = threadIdx.x; i < BBT * nslots * M_; i += 256) {
-                const int t = i / (nslots * M_), rem = i - t * (nslots * M_);
-                const int s = rem / M_, m = rem - s * M_;
-                const int64_t bb = base + t;
-                pl[(t * MAXS + s) * M_ + m] = bb < rend ? p.probs[(bb * H + h_first + s) * M_ + m] : 0.f;
-            }
-        }
-        // lhs blocks: column sums + transposed write
+        if (!u_block) {
+            if (POOLED) {
 #pragma unroll
-        for (int i = 0; i < NQL; ++i) {
-            const int q = threadIdx.x + 256 * i;
-            if (q < NBLK_L) {
-                const int fg = q % (BJ / NF), bg = q / (BJ / NF);
+                for (int i = 0; i < PLN; ++i) {
+                    const int idx = threadIdx.x + 256 * i;
+                    if (idx < BBT * MAXS * M_) pl[idx] = plr[i];
+                }
+            }
+            if (bgl < BG) {                               // lhs block: column sums + transposed write
 #pragma unroll
                 for (int t = 0; t < NR; ++t) {
                     float v[NF];
-                    Lb[i].get_row(t, v);
+                    Lb.get_row(t, v);
 #pragma unroll
                     for (int f = 0; f < NF; ++f) cs[f] += v[f];
                 }
-                Lb[i].store_t(ldsL, NF * fg, bg);
+                Lb.store_t(ldsL, NF * fgl, bgl);
             }
-        }
-        if (!POOLED) {
+            if (!POOLED) {
+                Rb[0].store_t(ldsR, NF * fgr, bgr);
+            } else {
+                __syncthreads();                          // probabilities visible
+                TBlk<T> P[MAXS];
 #pragma unroll
-            for (int i = 0; i < NQR; ++i) {
-                const int q = threadIdx.x + 256 * i;
-                if (q < NBLK_R) Rb[i][0].store_t(ldsR, NF * (q % FG), q / FG);
-            }
-            __syncthreads();
-        } else {
-            __syncthreads();                              // pl visible
+                for (int t = 0; t < NR; ++t) {
+                    float xv[M_][NF];                     // one batch row of every modality, unpacked once
 #pragma unroll
-            for (int i = 0; i < NQR; ++i) {
-                const int q = threadIdx.x + 256 * i;
-                if (q < NBLK_R) {
-                    const int fg = q % FG, bg = q / FG;
-                    for (int s = 0; s < nslots; ++s) {
-                        TBlk<T> P;
+                    for (int m = 0; m < M_; ++m) Rb[m].get_row(t, xv[m]);
 #pragma unroll
-                        for (int t = 0; t < NR; ++t) {
-                            const float* pr = pl + ((NR * bg + t) * MAXS + s) * M_;
-                            float pv[NF], xv[NF];
-                            Rb[i][0].get_row(t, xv);
+                    for (int s = 0; s < MAXS; ++s) {
+                        if (s < nslots) {
+                            const float* pr = pl + ((NR * bgr + t) * MAXS + s) * M_;
+                            float pv[NF];
                             const float p0 = pr[0];
 #pragma unroll
-                            for (int f = 0; f < NF; ++f) pv[f] = p0 * xv[f];
+                            for (int f = 0; f < NF; ++f) pv[f] = p0 * xv[0][f];
 #pragma unroll
                             for (int m = 1; m < M_; ++m) {
-                                Rb[i][m].get_row(t, xv);
                                 const float pm = pr[m];
 #pragma unroll
-                                for (int f = 0; f < NF; ++f) pv[f] = fmaf(pm, xv[f], pv[f]);
+                                for (int f = 0; f < NF; ++f) pv[f] = fmaf(pm, xv[m][f], pv[f]);
                             }
-                            P.set_row(t, pv);
+                            P[s].set_row(t, pv);
                         }
-                        P.store_t(ldsR + s * 128 * TILE_ROW_BYTES, NF * fg, bg);
                     }
                 }
+#pragma unroll
+                for (int s = 0; s < MAXS; ++s)
+                    if (s < nslots) P[s].store_t(ldsR + s * 128 * TILE_ROW_BYTES, NF * fgr, bgr);
             }
+            if (base + BBT < rend) load_step(base + BBT);         // next step's loads fly from here on
             __syncthreads();
-        }
-
-        // raw loads of the next step fly during the MFMAs (u needs this step's raw x first)
-        if (do_u) {
-            // u[h][k] += sum_m ds[.,h,m]^T x_m : one modality at a time through the raw x tile
-#pragma unroll
-            for (int m = 0; m < M_; ++m) {
-#pragma unroll
-                for (int i = 0; i < NQR; ++i) {
-                    const int q = threadIdx.x + 256 * i;
-                    if (q < NBLK_R) Rb[i][POOLED ? m : 0].store_t(ldsX, NF * (q % FG), q / FG);
-                }
-                __syncthreads();
+            if (wave_on) {
+                const char* rt_tile = ldsR + wslot * 128 * TILE_ROW_BYTES;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    float dv[X::EPL], dl[X::EPL];
+                    frag a[RT];
 #pragma unroll
-                    for (int e = 0; e < X::EPL; ++e) {
-                        const int64_t bb = base + X::EPL * (4 * ks + lg) + e;
-                        dv[e] = (bb < rend && r16 < H) ? p.dsbuf[(bb * H + r16) * M_ + m] : 0.f;
-                    }
-                    frag dhi = X::pack(dv), dlo = dhi;
-                    if (X::BYTES == 2) {
-                        float hv[X::EPL];
-                        X::unpack(dhi, hv);
+                    for (int rt = 0; rt < RT; ++rt) a[rt] = lds_frag<T>(ldsL, j0w + 16 * rt + r16, 4 * ks + lg);
 #pragma unroll
-                        for (int e = 0; e < X::EPL; ++e) dl[e] = dv[e] - hv[e];
-                        dlo = X::pack(dl);
-                    }
+                    for (int ct = 0; ct < CT; ++ct) {
+                        if (ct < nct) {
+                            frag b = lds_frag<T>(rt_tile, k0w + 16 * ct + r16, 4 * ks + lg);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int col0 = 32 * w + 16 * c;
-                        if (col0 < kcols) {
-                            frag xb = lds_frag<T>(ldsX, col0 + r16, 4 * ks + lg);
-                            uacc[c] = X::mma(dhi, xb, uacc[c]);
-                            if (X::BYTES == 2) uacc[c] = X::mma(dlo, xb, uacc[c]);
+                            for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = X::mma(a[rt], b, acc[rt][ct]);
                         }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        if (base + BBT < rend) load_step(base + BBT);
-        if (wave_on) {
-            const char* rt_tile = ldsR + wslot * 128 * TILE_ROW_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                frag a[RT];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[rt] = lds_frag<T>(ldsL, j0w + 16 * rt + r16, 4 * ks + lg);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    if (ct < nct) {
-                        frag b = lds_frag<T>(rt_tile, k0w + 16 * ct + r16, 4 * ks + lg);
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = X::mma(a[rt], b, acc[rt][ct]);
                     }
                 }
             }
         }
     }
+
 
     // ---- slab stores: acc[rt][ct][r] = out[j0 + j0w + 16 rt + 4 lg + r][k0 + k0w + 16 ct + r16] ----
     float* out = p.out + (int64_t)split * E * E;
@@ -293,17 +244,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
                         out[(int64_t)(j0 + j0w + 16 * rt + 4 * lg + r) * E + k0 + k0w + 16 * ct + r16] = acc[rt][ct][r];
                 }
     }
-    // column sums: thread (fg, bg) holds partial sums of its NB features over its batch rows; fold the 8 bg in order
+    // column sums: thread (fg, bg) holds partial sums of its NF features over its batch rows; fold the bg in order
     if (blockIdx.x == 0 && p.colsum) {
         __syncthreads();
+        if (bgl < BG) {
 #pragma unroll
-        for (int i = 0; i < NQL; ++i) {
-            const int q = threadIdx.x + 256 * i;
-            if (NQL == 1 && q < NBLK_L) {
-                const int fg = q % (BJ / NF), bg = q / (BJ / NF);
-#pragma unroll
-                for (int f = 0; f < NF; ++f) csl[bg * BJ + NF * fg + f] = cs[f];
-            }
+            for (int f = 0; f < NF; ++f) csl[bgl * BJ + NF * fgl + f] = cs[f];
         }
         __syncthreads();
         for (int j = threadIdx.x; j < jrows; j += 256) {
@@ -313,38 +259,142 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
             p.colsum[(int64_t)split * E + j0 + j] = a;
         }
     }
-    if (do_u) {
-        float* u = p.u + (int64_t)split * HPAD * E;
+}
+
+// u[split][h][k] = sum_{b in split} sum_m ds[b,h,m] x[b,m,k]  (key-side gradient; dW_k,h = qs_h (x) u[h]).
+// Same transposed staging as above for the raw x tiles (one LDS tile per modality); the A operand (rows =
+// heads) is built in registers from ds, as a bf16 hi/lo pair so the small ds values keep ~16 bits.
+// grid (ceil(E/128), 1, S); block 256: wave w owns column tiles 2w, 2w+1 of the 128 k columns.
+template <typename T, int M_>
+__global__ __launch_bounds__(256) void gemm_tn_u_kernel(GemmTnArgs p) {
+    using X = Tr<T>;
+    typedef typename X::frag frag;
+    constexpr int NR = TBlk<T>::NR, NF = TBlk<T>::NF;
+    constexpr int BBT = TileK<T>::value;
+    constexpr int FG = 128 / NF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // M_ tiles of [128][128 B]
+    const int E = p.E, H = p.H;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    const int k0 = blockIdx.x * 128;
+    const int split = blockIdx.z;
+    const int64_t rbeg = (int64_t)split * p.rows_per_split;
+    const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
+    const int kcols = (E - k0) >= 128 ? 128 : (E - k0);
+    const int fgr = threadIdx.x % FG, bgr = threadIdx.x / FG;
+    const bool r_on = NF * fgr < kcols;
+    const char* rhs = reinterpret_cast<const char*>(p.rhs);
+    const int64_t ldr = (int64_t)M_ * E * X::BYTES;
+    f32x4 uacc[2];
+    uacc[0] = uacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    TBlk<T> Rb[M_];
+    auto load_step = [&](int64_t base) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col0 = 32 * w + 16 * c;
-            if (col0 < kcols) {
+        for (int m = 0; m < M_; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) u[(int64_t)(4 * lg + r) * E + k0 + col0 + r16] = uacc[c][r];
+            for (int t = 0; t < NR; ++t) {
+                const int64_t bb = base + NR * bgr + t;
+                if (r_on && bb < rend) Rb[m].load_row(t, rhs + bb * ldr + ((int64_t)m * E + k0 + NF * fgr) * X::BYTES);
+                else Rb[m].zero_row(t);
             }
+    };
+    load_step(rbeg);
+    for (int64_t base = rbeg; base < rend; base += BBT) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M_; ++m) Rb[m].store_t(smem + m * 128 * TILE_ROW_BYTES, NF * fgr, bgr);
+        if (base + BBT < rend) load_step(base + BBT);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float dv[X::EPL], dl[X::EPL];
+#pragma unroll
+                for (int e = 0; e < X::EPL; ++e) {
+                    const int64_t bb = base + X::EPL * (4 * ks + lg) + e;
+                    dv[e] = (bb < rend && r16 < H) ? p.dsbuf[(bb * H + r16) * M_ + m] : 0.f;
+                }
+                frag dhi = X::pack(dv), dlo = dhi;
+                if (X::BYTES == 2) {
+                    float hv[X::EPL];
+                    X::unpack(dhi, hv);
+#pragma unroll
+                    for (int e = 0; e < X::EPL; ++e) dl[e] = dv[e] - hv[e];
+                    dlo = X::pack(dl);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int col0 = 32 * w + 16 * c;
+                    if (col0 < kcols) {
+                        frag xb = lds_frag<T>(smem + m * 128 * TILE_ROW_BYTES, col0 + r16, 4 * ks + lg);
+                        uacc[c] = X::mma(dhi, xb, uacc[c]);
+                        if (X::BYTES == 2) uacc[c] = X::mma(dlo, xb, uacc[c]);
+                    }
+                }
+            }
+        }
+    }
+    float* u = p.u + (int64_t)split * HPAD * E;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int col0 = 32 * w + 16 * c;
+        if (col0 < kcols) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[(int64_t)(4 * lg + r) * E + k0 + col0 + r16] = uacc[c][r];
         }
     }
 }
 
-template <typename T, int M_, bool POOLED, int WJ>
-static void launch_one(const GemmTnArgs& a, hipStream_t s) {
-    constexpr int BJ = (WJ == 16) ? 64 : 128;
-    constexpr int BBT = TileK<T>::value;
-    size_t smem = (size_t)BJ * TILE_ROW_BYTES + (size_t)(POOLED ? 4 : 1) * 128 * TILE_ROW_BYTES;
-    if (POOLED) smem += 128 * TILE_ROW_BYTES + (size_t)BBT * 4 * M_ * sizeof(float);
-    smem += (size_t)16 * BJ * sizeof(float);
-    dim3 grid((a.E + 127) / 128, (a.E + BJ - 1) / BJ, a.splits), block(256);
-    auto kern = gemm_tn_kernel<T, M_, POOLED, WJ>;
+template <typename T, int M_>
+static void launch_u(const GemmTnArgs& a, hipStream_t s) {
+    const size_t smem = (size_t)M_ * 128 * TILE_ROW_BYTES;
+    dim3 grid((a.E + 127) / 128, 1, a.splits), block(256);
+    auto kern = gemm_tn_u_kernel<T, M_>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     kern<<<grid, block, smem, s>>>(a);
 }
 
+template <typename T, int M_, bool POOLED, int WJ, int MAXS>
+static void launch_one(const GemmTnArgs& a, hipStream_t s) {
+    constexpr int BJ = (WJ == 16) ? 64 : 128;
+    constexpr int BBT = TileK<T>::value;
+    size_t smem = (size_t)BJ * TILE_ROW_BYTES + (size_t)(POOLED ? MAXS : 1) * 128 * TILE_ROW_BYTES;
+    if (POOLED) smem += (size_t)BBT * MAXS * M_ * sizeof(float);
+    smem += (size_t)16 * BJ * sizeof(float);
+    const int nJ = (a.E + BJ - 1) / BJ;
+    dim3 grid((a.E + 127) / 128, nJ, a.splits), block(256);
+    auto kern = gemm_tn_kernel<T, M_, POOLED, WJ, MAXS>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a);
+}
+
+// head slots a block needs = the most heads any aligned BJ-row window of the E output rows touches
+static int max_slots(int E, int hd, int BJ) {
+    int mx = 1;
+    for (int j0 = 0; j0 < E; j0 += BJ) {
+        const int j1 = (j0 + BJ < E ? j0 + BJ : E) - 1;
+        const int n = j1 / hd - j0 / hd + 1;
+        if (n > mx) mx = n;
+    }
+    return mx;
+}
+
+template <typename T, int M_, bool POOLED, int WJ>
+static void launch_slots(const GemmTnArgs& a, hipStream_t s) {
+    if (!POOLED) { launch_one<T, M_, POOLED, WJ, 1>(a, s); return; }
+    const int ns = max_slots(a.E, a.hd, (WJ == 16) ? 64 : 128);
+    if (ns <= 1) launch_one<T, M_, POOLED, WJ, 1>(a, s);
+    else if (ns <= 2) launch_one<T, M_, POOLED, WJ, 2>(a, s);
+    else launch_one<T, M_, POOLED, WJ, 4>(a, s);
+}
+
 template <typename T, int M_, bool POOLED>
 static void launch_wj(const GemmTnArgs& a, hipStream_t s) {
-    if (!POOLED || a.hd % 64 == 0) launch_one<T, M_, POOLED, 64>(a, s);
-    else if (a.hd % 32 == 0) launch_one<T, M_, POOLED, 32>(a, s);
-    else launch_one<T, M_, POOLED, 16>(a, s);
+    if (!POOLED || a.hd % 64 == 0) launch_slots<T, M_, POOLED, 64>(a, s);
+    else if (a.hd % 32 == 0) launch_slots<T, M_, POOLED, 32>(a, s);
+    else launch_slots<T, M_, POOLED, 16>(a, s);
 }
 
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s) {
@@ -353,7 +403,8 @@ void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s) {
         return;
     }
     AECF_DISPATCH_M(a.M, {
-        if (dtype == 0) launch_wj<BF16, M_, true>(a, s); else launch_wj<F32, M_, true>(a, s);
+        if (dtype == 0) { launch_wj<BF16, M_, true>(a, s); launch_u<BF16, M_>(a, s); }
+        else { launch_wj<F32, M_, true>(a, s); launch_u<F32, M_>(a, s); }
     });
 }
 
