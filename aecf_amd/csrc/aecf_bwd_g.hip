@@ -24,34 +24,35 @@
 
 namespace aecf {
 
-constexpr int G_WAVES = 8;
+constexpr int G_SAMPLES = 128;               // samples per block
+constexpr int G_WAVES = 2 * (G_SAMPLES / 16);  // (sample tiles) x (2 row halves)
 constexpr int G_THREADS = 64 * G_WAVES;
 
 template <typename T, int M_, bool DX>
-__global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
+__global__ __launch_bounds__(G_THREADS) void bwd_g_kernel(BwdGArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
     constexpr int BK = TileK<T>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsA = smem;                               // [128][128 B]  W_v^T rows
     char* ldsB = smem + 128 * TILE_ROW_BYTES;        // [64][128 B]   do rows (samples)
-    float* fl = reinterpret_cast<float*>(smem + 192 * TILE_ROW_BYTES);
+    float* fl = reinterpret_cast<float*>(smem + (128 + G_SAMPLES) * TILE_ROW_BYTES);
     const int E = p.E, H = p.H, hd = p.hd;
     const int HM = H * M_;
     // DA: fl = da[64][H][M] | slot[2][2][64][M]        DX: fl = probs[64][H][M] | ds[64][H][M] | av[H][128]
-    float* slot = fl + 64 * HM;
-    float* avl = fl + 2 * 64 * HM;
+    float* slot = fl + G_SAMPLES * HM;
+    float* avl = fl + 2 * G_SAMPLES * HM;
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
-    const int64_t b0 = (int64_t)blockIdx.x * 64;
-    const int rows_b = (p.B - b0) >= 64 ? 64 : (int)(p.B - b0);
+    const int64_t b0 = (int64_t)blockIdx.x * G_SAMPLES;
+    const int rows_b = (p.B - b0) >= G_SAMPLES ? G_SAMPLES : (int)(p.B - b0);
 
     if (!DX) {
-        for (int i = threadIdx.x; i < 64 * HM; i += G_THREADS) fl[i] = 0.f;
+        for (int i = threadIdx.x; i < G_SAMPLES * HM; i += G_THREADS) fl[i] = 0.f;
     } else {
-        for (int i = threadIdx.x; i < 64 * HM; i += G_THREADS) {
+        for (int i = threadIdx.x; i < G_SAMPLES * HM; i += G_THREADS) {
             const bool ok = (i / HM) < rows_b;
             fl[i] = ok ? p.probs[b0 * HM + i] : 0.f;
-            fl[64 * HM + i] = ok ? p.dsbuf[b0 * HM + i] : 0.f;
+            fl[G_SAMPLES * HM + i] = ok ? p.dsbuf[b0 * HM + i] : 0.f;
         }
     }
 
@@ -62,13 +63,13 @@ __global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
     const char* dob = reinterpret_cast<const char*>(p.dobuf) + b0 * E * X::BYTES;
     const int64_t ld_bytes = (int64_t)E * X::BYTES;
 
-    const int ct = w & 3, rh = w >> 2;                           // this wave: samples 16ct.., E-row half rh
+    const int ct = w & (G_SAMPLES / 16 - 1), rh = w / (G_SAMPLES / 16);                           // this wave: samples 16ct.., E-row half rh
     const int srow = 16 * ct + r16;                              // sample (within the block) of this lane
     const int64_t bs = b0 + srow;
     const int64_t bcl = bs < p.B ? bs : p.B - 1;
 
     DirectStage<128, G_THREADS> sa;
-    DirectStage<64, G_THREADS> sb;
+    DirectStage<G_SAMPLES, G_THREADS> sb;
     int pending_h = -1;                                          // DA: head whose slots wait to be folded into da
 
     for (int kb = 0; kb < nkb; ++kb) {
@@ -116,10 +117,10 @@ __global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
                 }
             }
             if (!DX && pending_h >= 0) {                         // fold the previous head's two row-half partials
-                const float* sl = slot + (pending_h & 1) * (2 * 64 * M_);
-                for (int i = threadIdx.x; i < 64 * M_; i += G_THREADS) {
+                const float* sl = slot + (pending_h & 1) * (2 * G_SAMPLES * M_);
+                for (int i = threadIdx.x; i < G_SAMPLES * M_; i += G_THREADS) {
                     const int s = i / M_, m = i - s * M_;
-                    fl[s * HM + pending_h * M_ + m] += sl[i] + sl[64 * M_ + i];
+                    fl[s * HM + pending_h * M_ + m] += sl[i] + sl[G_SAMPLES * M_ + i];
                 }
                 pending_h = -1;
             }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
 
             // ---- g_h tile complete: acc[rt][0][r] = g_h[sample srow][E index krow + 16 rt + r] ----
             if (!DX) {
-                float* sl = slot + (h & 1) * (2 * 64 * M_) + rh * 64 * M_;
+                float* sl = slot + (h & 1) * (2 * G_SAMPLES * M_) + rh * G_SAMPLES * M_;
 #pragma unroll
                 for (int m = 0; m < M_; ++m) {
                     float s = 0.f;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
 #pragma unroll
                 for (int m = 0; m < M_; ++m) {
                     pm[m] = fl[srow * HM + h * M_ + m];
-                    dm[m] = fl[64 * HM + srow * HM + h * M_ + m];
+                    dm[m] = fl[G_SAMPLES * HM + srow * HM + h * M_ + m];
                 }
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
@@ -172,10 +173,10 @@ __global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
         if (!DX) {
             // fold the last head of this kb before the slots are reused by the next kb
             __syncthreads();
-            const float* sl = slot + (pending_h & 1) * (2 * 64 * M_);
-            for (int i = threadIdx.x; i < 64 * M_; i += G_THREADS) {
+            const float* sl = slot + (pending_h & 1) * (2 * G_SAMPLES * M_);
+            for (int i = threadIdx.x; i < G_SAMPLES * M_; i += G_THREADS) {
                 const int s = i / M_, m = i - s * M_;
-                fl[s * HM + pending_h * M_ + m] += sl[i] + sl[64 * M_ + i];
+                fl[s * HM + pending_h * M_ + m] += sl[i] + sl[G_SAMPLES * M_ + i];
             }
             pending_h = -1;
         } else if (wave_on && bs < p.B) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
         // ds[b,h,:] from the accumulated da (softmax backward), one (sample, head) pair per thread-iteration
         __syncthreads();
         const float invH = 1.0f / (float)H;
-        for (int i = threadIdx.x; i < 64 * H; i += G_THREADS) {
+        for (int i = threadIdx.x; i < G_SAMPLES * H; i += G_THREADS) {
             const int s = i / H, h = i - s * H;
             if (s >= rows_b) continue;
             const int64_t b = b0 + s;
@@ -227,9 +228,9 @@ __global__ __launch_bounds__(G_THREADS, 4) void bwd_g_kernel(BwdGArgs p) {
 template <typename T, int M_, bool DX>
 static void launch_one(const BwdGArgs& a, hipStream_t s) {
     const size_t HM = (size_t)a.H * a.M;
-    const size_t floats = DX ? (2 * 64 * HM + (size_t)a.H * 128) : (64 * HM + 2 * 2 * 64 * (size_t)a.M);
-    const size_t smem = (size_t)192 * TILE_ROW_BYTES + floats * sizeof(float);
-    dim3 grid((unsigned)((a.B + 63) / 64)), block(G_THREADS);
+    const size_t floats = DX ? (2 * G_SAMPLES * HM + (size_t)a.H * 128) : (G_SAMPLES * HM + 2 * 2 * G_SAMPLES * (size_t)a.M);
+    const size_t smem = (size_t)(128 + G_SAMPLES) * TILE_ROW_BYTES + floats * sizeof(float);
+    dim3 grid((unsigned)((a.B + G_SAMPLES - 1) / G_SAMPLES)), block(G_THREADS);
     auto kern = bwd_g_kernel<T, M_, DX>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
