@@ -347,7 +347,59 @@ def g9_validation():
     print("g9", len(cases))
 
 
+def g10_model_step():
+    """One training step of the reference's AECFModel (xrays/train_xrays_example.py:108-237, 360-377) on
+    synthetic CLIP-like features: curriculum masking on, dropout disabled (its RNG stream is device-specific),
+    some rows with a missing modality so that all three routing branches run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_xrays", "/root/reference/xrays/train_xrays_example.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.manual_seed(1010)
+    model = mod.AECFModel(image_dim=512, text_dim=512, num_classes=15, hidden_dim=256)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.toggle_curriculum(True)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    g = torch.Generator().manual_seed(1011)
+    B = 64
+    images = torch.randn(B, 512, generator=g)
+    texts = torch.randn(B, 512, generator=g)
+    images[5:12] = 0.0            # text only
+    texts[40:47] = 0.0            # image only
+    labels = (torch.rand(B, 15, generator=g) < 0.2).float()
+    n_both = B - 14
+    torch.manual_seed(1012)
+    U = torch.rand(n_both, 1, 2)
+    torch.manual_seed(1012)
+    logits, info = model(images, texts, return_info=True)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, labels)
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    np.savez_compressed(
+        os.path.join(HERE, "g10_model_step.npz"),
+        seed_model=1010, images=npy(images), texts=npy(texts), labels=npy(labels), uniforms=npy(U),
+        logits=npy(logits), loss=float(loss), entropy=npy(info["entropy"]), mask_rate=npy(info["mask_rate"]),
+        attention_weights=npy(info["attention_weights"]),
+        masked_attention_weights=npy(info["masked_attention_weights"]),
+        param_names=np.array(list(grads.keys())),
+        grad_norms=np.array([float(v.norm()) if v is not None else -1.0 for v in grads.values()]),
+        g_fusion_query=npy(grads["fusion_query"]),
+        g_in_proj_bias=npy(grads["attention_pool.attention.in_proj_bias"]),
+        g_out_proj_weight=npy(grads["attention_pool.attention.out_proj.weight"]),
+        g_image_encoder_bias=npy(grads["image_encoder.0.bias"]),
+        sd_keys=np.array(list(model.state_dict().keys())),
+        w_check=npy(model.classifier[3].weight)[0, :8])
+    print("g10 model step: loss", float(loss), "params", sum(p.numel() for p in model.parameters()))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        g10_model_step()
+        sys.exit(0)
     # fp32 inputs, full mantissa
     g2_case("e64h1m2", 64, 1, 2, 48, seed=1)
     g2_case("e64h4m3", 64, 4, 3, 64, seed=2)
@@ -370,3 +422,4 @@ if __name__ == "__main__":
     g7_functional()
     g8_options()
     g9_validation()
+    g10_model_step()
