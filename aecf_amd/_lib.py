@@ -86,6 +86,12 @@ _SYMBOLS = [
     ("aecf_sdpa_backward", c_int,
      [c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("aecf_l2norm_forward", c_int, [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("aecf_l2norm_backward", c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("aecf_nce_workspace_bytes", c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    ("aecf_nce_fwd_bwd", c_int,
+     [c_int64, c_int64, c_int64, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_void_p, c_size_t, c_void_p]),
 ]
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
 

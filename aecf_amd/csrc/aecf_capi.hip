@@ -176,13 +176,13 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     v.a = a->x; v.w = (const char*)a->w_in + (size_t)2 * E * E * es;
     v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
     v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
-    v.M = M; v.H = H; v.hd = hd; v.pooled = 1;
+    v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = 0;
     launch_gemm_nt(d->dtype, v, s);
     mark(ev, 3, s);
 
     GemmNtArgs y;
     y.a = o; y.w = a->w_out; y.bias = a->b_out; y.c = a->y; y.probs = nullptr; y.R = d->batch; y.N = E; y.K = E;
-    y.lda = E; y.M = 1; y.H = H; y.hd = hd; y.pooled = 0;
+    y.lda = E; y.M = 1; y.H = H; y.hd = hd; y.pooled = 0; y.out_f32 = 0;
     launch_gemm_nt(d->dtype, y, s);
     mark(ev, 4, s);
     return launch_status();
@@ -222,7 +222,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     // do = dy W_o   (NT GEMM against W_o^T)
     GemmNtArgs g;
     g.a = a->dy; g.w = wot; g.bias = nullptr; g.c = dobuf; g.probs = nullptr; g.R = B; g.N = E; g.K = E; g.lda = E;
-    g.M = 1; g.H = H; g.hd = hd; g.pooled = 0;
+    g.M = 1; g.H = H; g.hd = hd; g.pooled = 0; g.out_f32 = 0;
     launch_gemm_nt(d->dtype, g, s);
     mark(ev, 2, s);
 
@@ -230,7 +230,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     GemmTnArgs t1;
     t1.lhs = a->dy; t1.rhs = a->saved_o; t1.probs = nullptr; t1.dsbuf = nullptr; t1.out = (float*)(ws + L.slab_o);
     t1.colsum = (float*)(ws + L.cs_o); t1.u = nullptr; t1.B = B; t1.M = 1; t1.E = E; t1.H = H; t1.hd = hd;
-    t1.splits = L.splits; t1.rows_per_split = L.rows_per_split; t1.pooled = 0;
+    t1.Ej = 0; t1.splits = L.splits; t1.rows_per_split = L.rows_per_split; t1.pooled = 0;
     launch_gemm_tn(d->dtype, t1, s);
     mark(ev, 3, s);
 
@@ -247,7 +247,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     GemmTnArgs t2;
     t2.lhs = dobuf; t2.rhs = a->x; t2.probs = a->saved_probs; t2.dsbuf = dsbuf; t2.out = (float*)(ws + L.slab_v);
     t2.colsum = (float*)(ws + L.cs_v); t2.u = (float*)(ws + L.u_slab); t2.B = B; t2.M = M; t2.E = E; t2.H = H;
-    t2.hd = hd; t2.splits = L.splits; t2.rows_per_split = L.rows_per_split; t2.pooled = 1;
+    t2.hd = hd; t2.Ej = 0; t2.splits = L.splits; t2.rows_per_split = L.rows_per_split; t2.pooled = 1;
     launch_gemm_tn(d->dtype, t2, s);
     mark(ev, 6, s);
 
@@ -322,6 +322,64 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
     if (S > 64 || T > 64 || (dtype != AECF_BF16 && dtype != AECF_F32)) return AECF_ERR_UNSUPPORTED;
     if (!q || !k || !v || !probs || !dout || !dq || !dk || !dv) return AECF_ERR_NULL_POINTER;
     launch_sdpa_bwd(dtype, B, S, T, E, scale, q, k, v, probs, dout, dq, dk, dv, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_l2norm_forward(int64_t n, int32_t d, int32_t dtype, float eps, const void* z, void* zn, float* inv_norm,
+                        void* stream) {
+    if (n <= 0 || d <= 0) return AECF_ERR_BAD_DIMS;
+    if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (!z || !zn || !inv_norm) return AECF_ERR_NULL_POINTER;
+    launch_l2norm_fwd(dtype, n, d, eps, z, zn, inv_norm, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_l2norm_backward(int64_t n, int32_t d, int32_t dtype, const void* zn, const float* inv_norm, const float* dzn,
+                         void* dz, void* stream) {
+    if (n <= 0 || d <= 0) return AECF_ERR_BAD_DIMS;
+    if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (!zn || !inv_norm || !dzn || !dz) return AECF_ERR_NULL_POINTER;
+    launch_l2norm_bwd(dtype, n, d, zn, inv_norm, dzn, dz, (hipStream_t)stream);
+    return launch_status();
+}
+
+size_t aecf_nce_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype) {
+    if (rows <= 0 || cols <= 0 || d <= 0) return 0;
+    const size_t es = esize(dtype);
+    return align_up((size_t)rows * cols * 4) + align_up((size_t)rows * cols * es) + align_up((size_t)d * cols * es);
+}
+
+int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, int32_t dtype, float temperature,
+                     float coef, const void* q, const void* k, float* loss_rows, float* dq, float* dk, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (rows <= 0 || cols <= 0 || d <= 0 || temperature <= 0.f) return AECF_ERR_BAD_DIMS;
+    if (row_offset < 0 || row_offset + rows > cols) return AECF_ERR_BAD_DIMS;
+    if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (d % 64 != 0 || cols % 64 != 0) return AECF_ERR_UNSUPPORTED;
+    if (!q || !k || !loss_rows || !dq || !dk || !workspace) return AECF_ERR_NULL_POINTER;
+    if (workspace_bytes < aecf_nce_workspace_bytes(rows, cols, d, dtype)) return AECF_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t es = esize(dtype);
+    char* ws = (char*)workspace;
+    float* S = (float*)ws;
+    void* G = ws + align_up((size_t)rows * cols * 4);
+    void* kT = (char*)G + align_up((size_t)rows * cols * es);
+
+    GemmNtArgs g1;       // S = q k^T  (float32 logits before the temperature)
+    g1.a = q; g1.w = k; g1.bias = nullptr; g1.c = S; g1.probs = nullptr; g1.R = rows; g1.N = (int)cols; g1.K = d;
+    g1.lda = d; g1.M = 1; g1.H = 1; g1.hd = d; g1.pooled = 0; g1.out_f32 = 1;
+    launch_gemm_nt(dtype, g1, s);
+    launch_nce_rows(dtype, rows, cols, row_offset, 1.0f / temperature, coef, S, G, loss_rows, s);
+    launch_transpose_rect(dtype, k, kT, cols, d, s);
+    GemmNtArgs g2;       // dq = G k
+    g2.a = G; g2.w = kT; g2.bias = nullptr; g2.c = dq; g2.probs = nullptr; g2.R = rows; g2.N = d; g2.K = (int)cols;
+    g2.lda = cols; g2.M = 1; g2.H = 1; g2.hd = d; g2.pooled = 0; g2.out_f32 = 1;
+    launch_gemm_nt(dtype, g2, s);
+    GemmTnArgs t;        // dk = G^T q   (reduction over the local rows)
+    t.lhs = G; t.rhs = q; t.probs = nullptr; t.dsbuf = nullptr; t.out = dk; t.colsum = nullptr; t.u = nullptr;
+    t.B = rows; t.M = 1; t.E = d; t.H = 1; t.hd = d; t.Ej = (int)cols; t.splits = 1;
+    t.rows_per_split = (rows + 63) / 64 * 64; t.pooled = 0;
+    launch_gemm_tn(dtype, t, s);
     return launch_status();
 }
 

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         const int n = nw0 + 16 * ct + r16;
         bv[ct] = (bias && ct < nct) ? X::to_f32(bias[n]) : 0.f;
     }
-    if (X::BYTES == 2) {
+    if (X::BYTES == 2 && !p.out_f32) {
         // accumulators -> LDS as a [128][128] bf16 image (256-byte rows), then full-row 16-byte stores
         __syncthreads();
         char* cl = smem;
@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t row = r0 + 64 * wr + 16 * rt + 4 * lg + r;
-                        if (row < p.R) c[row * p.N + n] = X::from_f32(acc[rt][ct][r] + bv[ct]);
+                        if (row < p.R) {
+                            if (p.out_f32) reinterpret_cast<float*>(p.c)[row * p.N + n] = acc[rt][ct][r] + bv[ct];
+                            else c[row * p.N + n] = X::from_f32(acc[rt][ct][r] + bv[ct]);
+                        }
                     }
             }
         }

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int E = p.E, H = p.H;
+    const int EJ = p.Ej > 0 ? p.Ej : p.E;                // lhs features = output rows (E = rhs features = output cols)
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
 
     constexpr bool u_block = false;                               // (u has its own kernel below)
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
     const int split = blockIdx.z;
     const int64_t rbeg = (int64_t)split * p.rows_per_split;
     const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
-    const int jrows = (E - j0) >= BJ ? BJ : (E - j0);    // valid j rows / k cols of this block (multiples of 64)
+    const int jrows = (EJ - j0) >= BJ ? BJ : (EJ - j0);    // valid j rows / k cols of this block (multiples of 64)
     const int kcols = (E - k0) >= 128 ? 128 : (E - k0);
 
     const int h_first = POOLED ? j0 / p.hd : 0;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 
     const char* lhs = reinterpret_cast<const char*>(p.lhs);
     const char* rhs = reinterpret_cast<const char*>(p.rhs);
-    const int64_t ldl = (int64_t)E * X::BYTES;
+    const int64_t ldl = (int64_t)EJ * X::BYTES;
     const int64_t ldr = (int64_t)(POOLED ? M_ : 1) * E * X::BYTES;
 
     // this thread's register block: feature group fg, batch group bg (both tiles use the same indices)
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 
 
     // ---- slab stores: acc[rt][ct][r] = out[j0 + j0w + 16 rt + 4 lg + r][k0 + k0w + 16 ct + r16] ----
-    float* out = p.out + (int64_t)split * E * E;
+    float* out = p.out + (int64_t)split * EJ * E;
     if (wave_on) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
             float a = 0.f;
 #pragma unroll
             for (int bg = 0; bg < BG; ++bg) a += csl[bg * BJ + j];
-            p.colsum[(int64_t)split * E + j0 + j] = a;
+            p.colsum[(int64_t)split * EJ + j0 + j] = a;
         }
     }
 }
@@ -362,7 +363,7 @@ static void launch_one(const GemmTnArgs& a, hipStream_t s) {
     size_t smem = (size_t)BJ * TILE_ROW_BYTES + (size_t)(POOLED ? MAXS : 1) * 128 * TILE_ROW_BYTES;
     if (POOLED) smem += (size_t)BBT * MAXS * M_ * sizeof(float);
     smem += (size_t)16 * BJ * sizeof(float);
-    const int nJ = (a.E + BJ - 1) / BJ;
+    const int nJ = ((a.Ej > 0 ? a.Ej : a.E) + BJ - 1) / BJ;
     dim3 grid((a.E + 127) / 128, nJ, a.splits), block(256);
     auto kern = gemm_tn_kernel<T, M_, POOLED, WJ, MAXS>;
     if (smem > 64 * 1024)

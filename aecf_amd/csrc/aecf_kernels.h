@@ -51,6 +51,7 @@ struct GemmNtArgs {
     int64_t lda;
     int M, H, hd;
     int pooled;
+    int out_f32;         // store C as float32 regardless of dtype (logits)
 };
 void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
 
@@ -90,6 +91,7 @@ struct GemmTnArgs {
     float* u;             // [S,HPAD,E] pooled
     int64_t B;
     int M, E, H, hd;
+    int Ej;               // lhs feature count when it differs from E (rectangular, non-pooled); 0 = E
     int splits;           // S
     int64_t rows_per_split;   // multiple of 32
     int pooled;
@@ -134,5 +136,16 @@ void launch_sdpa_fwd(int dtype, int64_t B, int S, int T, int E, float scale, con
                      void* out, float* probs, hipStream_t s);
 void launch_sdpa_bwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,
                      const float* probs, const void* dout, void* dq, void* dk, void* dv, hipStream_t s);
+
+// ---------------- contrastive (aecf_contrastive.hip) ----------------
+void launch_l2norm_fwd(int dtype, int64_t n, int d, float eps, const void* z, void* zn, float* inv_norm, hipStream_t s);
+void launch_l2norm_bwd(int dtype, int64_t n, int d, const void* zn, const float* inv_norm, const float* dzn, void* dz,
+                       hipStream_t s);
+// per local row i: logits = S[i,:] * inv_temp; loss_rows[i] = logsumexp - logits[row_offset + i];
+// G[i,:] = (softmax - onehot) * coef * inv_temp   (dtype)
+void launch_nce_rows(int dtype, int64_t rows, int64_t cols, int64_t row_offset, float inv_temp, float coef, const float* S,
+                     void* G, float* loss_rows, hipStream_t s);
+// dst[c][r] = src[r][c]   (R x C, dtype; R, C multiples of 32)
+void launch_transpose_rect(int dtype, const void* src, void* dst, int64_t R, int64_t C, hipStream_t s);
 
 }  // namespace aecf

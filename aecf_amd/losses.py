@@ -1,0 +1,132 @@
+"""The loss side of the AECF objective: the entropy regulariser of the reference
+(``CurriculumMasking.entropy_loss``, ref aecf/AECFLayer.py:285-314) plus the contrastive term that
+BASELINE.json's north_star names.
+
+The contrastive term does NOT exist in the reference; it is build-defined here as
+the symmetric InfoNCE of two views' fused embeddings, L2-normalised, with cross-batch negatives all-gathered
+over the data-parallel group:
+
+    L = 0.5 / B_all * sum_i [ CE(za_i . zb_all / T, i) + CE(zb_i . za_all / T, i) ]
+
+All arithmetic (normalisation, logits GEMM, softmax / loss rows, both gradient GEMMs) runs in libaecf_hip.so;
+the exchange steps are ``dp.all_gather_rows`` (forward) and its reduce-scatter (backward).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib, dp
+from .layer import _DTYPES, _ptr, _require_device, _stream, CurriculumMasking
+
+
+class _L2Norm(torch.autograd.Function):
+    """aecf_l2norm_forward / _backward: rows -> unit norm."""
+
+    @staticmethod
+    def forward(ctx, z, eps):
+        lib = _lib.load()
+        n, d = z.shape
+        zc = z.contiguous()
+        zn = torch.empty_like(zc)
+        inv = torch.empty(n, dtype=torch.float32, device=z.device)
+        _lib.check(lib.aecf_l2norm_forward(n, d, _DTYPES[z.dtype], eps, _ptr(zc), _ptr(zn), _ptr(inv), _stream()),
+                   "aecf_l2norm_forward")
+        ctx.save_for_backward(zn, inv)
+        return zn
+
+    @staticmethod
+    def backward(ctx, dzn):
+        lib = _lib.load()
+        zn, inv = ctx.saved_tensors
+        n, d = zn.shape
+        g = dzn.to(torch.float32).contiguous()
+        dz = torch.empty_like(zn)
+        _lib.check(lib.aecf_l2norm_backward(n, d, _DTYPES[zn.dtype], _ptr(zn), _ptr(inv), _ptr(g), _ptr(dz), _stream()),
+                   "aecf_l2norm_backward")
+        return dz, None
+
+
+class _NceDirection(torch.autograd.Function):
+    """aecf_nce_fwd_bwd: sum_i [logsumexp_j(q_i.k_j/T) - q_i.k_{off+i}/T] * coef for local unit-norm q against all k.
+    Forward and both gradients come out of the same call (the gradients are linear in the upstream scalar)."""
+
+    @staticmethod
+    def forward(ctx, q, k_all, row_offset, temperature, coef):
+        lib = _lib.load()
+        rows, d = q.shape
+        cols = k_all.shape[0]
+        dt = q.dtype
+        qc, kc = q.contiguous(), k_all.to(dt).contiguous()
+        dev = q.device
+        loss_rows = torch.empty(rows, dtype=torch.float32, device=dev)
+        dq = torch.empty(rows, d, dtype=torch.float32, device=dev)
+        dk = torch.empty(cols, d, dtype=torch.float32, device=dev)
+        ws_bytes = lib.aecf_nce_workspace_bytes(rows, cols, d, _DTYPES[dt])
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.aecf_nce_fwd_bwd(rows, cols, row_offset, d, _DTYPES[dt], temperature, coef, _ptr(qc), _ptr(kc),
+                                        _ptr(loss_rows), _ptr(dq), _ptr(dk), _ptr(ws), ws_bytes, _stream()),
+                   "aecf_nce_fwd_bwd")
+        ctx.save_for_backward(dq, dk)
+        ctx.dtypes = (q.dtype, k_all.dtype)
+        return loss_rows.sum() * coef
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dq, dk = ctx.saved_tensors
+        g = dloss.to(torch.float32)
+        return (dq * g).to(ctx.dtypes[0]), (dk * g).to(ctx.dtypes[1]), None, None, None
+
+
+def l2_normalize(z: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    _require_device(z, "z")
+    return _L2Norm.apply(z, float(eps))
+
+
+def info_nce(za: torch.Tensor, zb: torch.Tensor, temperature: float = 0.07, group=None) -> torch.Tensor:
+    """Symmetric InfoNCE between the local rows of two views with negatives from every rank of ``group``.
+    ``za``, ``zb``: [b_local, d] on a ROCm device, d % 64 == 0, total rows over ranks % 64 == 0."""
+    _require_device(za, "za")
+    _require_device(zb, "zb")
+    if za.shape != zb.shape or za.dim() != 2:
+        raise ValueError(f"info_nce expects two [b, d] tensors of equal shape, got {tuple(za.shape)} and {tuple(zb.shape)}")
+    if za.dtype not in _DTYPES:
+        raise NotImplementedError(f"aecf_amd: dtype {za.dtype} is not supported (bfloat16 / float32 only)")
+    rank, world = dp.world_info(group)
+    na, nb = l2_normalize(za), l2_normalize(zb)
+    na_all = dp.all_gather_rows(na, group) if world > 1 else na
+    nb_all = dp.all_gather_rows(nb, group) if world > 1 else nb
+    b_all = na_all.shape[0]
+    if world > 1:
+        sizes = torch.tensor([za.shape[0]], device=za.device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        torch.distributed.all_gather(all_sizes, sizes, group=group)
+        offset = int(sum(int(s.item()) for s in all_sizes[:rank]))
+    else:
+        offset = 0
+    coef = 0.5 / float(b_all)
+    l_ab = _NceDirection.apply(na, nb_all, offset, float(temperature), coef)
+    l_ba = _NceDirection.apply(nb, na_all, offset, float(temperature), coef)
+    share = l_ab + l_ba                  # this rank's rows' share of the global objective
+    if world == 1:
+        return share
+    # Data-parallel convention (dp.FlatGradBucket.all_reduce(average=True)): gradients are AVERAGED over ranks, so
+    # the local term carries a factor `world`; the returned VALUE is the global loss on every rank.
+    total = share.detach().clone()
+    torch.distributed.all_reduce(total, group=group)
+    scaled = share * world
+    return scaled + (total - scaled.detach())
+
+
+def fusion_objective(task_loss: torch.Tensor, masking: Optional[CurriculumMasking], entropy: Optional[torch.Tensor],
+                     za: Optional[torch.Tensor] = None, zb: Optional[torch.Tensor] = None, entropy_weight: float = 0.01,
+                     contrastive_weight: float = 1.0, temperature: float = 0.07, group=None) -> torch.Tensor:
+    """task + entropy_weight * entropy_loss(entropy) [ref README.md:205-208] + contrastive_weight * info_nce(za, zb)."""
+    total = task_loss
+    if masking is not None and entropy is not None:
+        total = total + entropy_weight * masking.entropy_loss(entropy)
+    if za is not None and zb is not None:
+        total = total + contrastive_weight * info_nce(za, zb, temperature, group)
+    return total

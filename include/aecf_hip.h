@@ -161,6 +161,23 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
                        const void* q, const void* k, const void* v, const float* probs,
                        const void* dout, void* dq, void* dk, void* dv, void* stream);
 
+/* ---- contrastive term (BASELINE.json north_star; NOT in the reference: SURVEY.md 8a row A9, build-defined) ----
+ * Row-wise L2 normalisation zn = z / max(||z||, eps) and its backward dz = (dzn - zn (dzn.zn)) * inv_norm. */
+int aecf_l2norm_forward(int64_t n, int32_t d, int32_t dtype, float eps, const void* z, void* zn,
+                        float* inv_norm, void* stream);
+int aecf_l2norm_backward(int64_t n, int32_t d, int32_t dtype, const void* zn, const float* inv_norm,
+                         const float* dzn, void* dz, void* stream);
+/* One InfoNCE direction, forward + backward in one call: local unit-norm queries q [rows,d] against all
+ * (all-gathered) unit-norm keys k [cols,d]; the positive of local row i is key row_offset + i.
+ *   loss_rows[i] = logsumexp_j(q_i.k_j / T) - q_i.k_pos / T                       float32 [rows]
+ *   dq = coef/T * (softmax - onehot) k          float32 [rows,d]
+ *   dk = coef/T * (softmax - onehot)^T q        float32 [cols,d]   (sum over ranks is the caller's reduce-scatter)
+ * d % 64 == 0, cols % 64 == 0. */
+size_t aecf_nce_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype);
+int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, int32_t dtype,
+                     float temperature, float coef, const void* q, const void* k, float* loss_rows,
+                     float* dq, float* dk, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
