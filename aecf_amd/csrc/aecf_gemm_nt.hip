@@ -13,6 +13,8 @@
 // MFMA input type), so V is projected once per sample instead of once per (sample, modality).
 //
 // bf16 output leaves through LDS as full 256-byte rows; f32 output is stored from the accumulator layout.
+#include <stdlib.h>
+
 #include "aecf_kernels.h"
 #include "aecf_tile.h"
 
@@ -32,8 +34,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     const int wr = w >> 1, wc = w & 1;
-    const int64_t r0 = (int64_t)blockIdx.x * 128;
-    const int n0 = blockIdx.y * 128;
+    unsigned int panel, coltile;
+    if (!xcd_tile(blockIdx.x, (unsigned)((p.R + 127) / 128), (unsigned)((p.N + 127) / 128), panel, coltile)) return;
+    const int64_t r0 = (int64_t)panel * 128;
+    const int n0 = coltile * 128;
     const int rows_valid = (p.R - r0) >= 128 ? 128 : (int)(p.R - r0);
     const int cols_valid = (p.N - n0) >= 128 ? 128 : (p.N - n0);
     const int K = p.K;
@@ -83,14 +87,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         for (int m = 0; m < NA; ++m) sa[m].store(ldsA + m * TILE);
         sb.store(ldsB);
         __syncthreads();
-        if (kt + 1 < nkt) {                    // next tile's loads fly during the MFMAs below
+        if (kt + 1 < nkt && !(p.pooled & 1024)) {                    // next tile's loads fly during the MFMAs below
             const int64_t koff = (int64_t)(kt + 1) * TILE_ROW_BYTES;
 #pragma unroll
             for (int m = 0; m < NA; ++m) sa[m].load(a_src + (int64_t)m * K * X::BYTES + koff, lda_bytes, rows_valid);
             sb.load(w_src + koff, ldw_bytes, cols_valid);
         }
         if (!POOLED) {
-            tile_mma<T, 4, 4>(acc, ldsA, 64 * wr, ldsB, 64 * wc);
+            if (!(p.pooled & 512)) tile_mma<T, 4, 4>(acc, ldsA, 64 * wr, ldsB, 64 * wc);
         } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         }
     }
 
+    if (p.pooled & 256) return;
     // ---------------- epilogue ----------------
     const elem* bias = reinterpret_cast<const elem*>(p.bias);
     float bv[4];
@@ -191,21 +196,19 @@ template <typename T, int M_, bool POOLED>
 static void launch_one(const GemmNtArgs& a, hipStream_t s) {
     constexpr int NA = POOLED ? M_ : 1;
     const size_t smem = (size_t)(NA + 1) * 128 * TILE_ROW_BYTES;
-    dim3 grid((unsigned)((a.R + 127) / 128), (a.N + 127) / 128), block(256);
+    dim3 grid(xcd_grid((unsigned)((a.R + 127) / 128), (unsigned)((a.N + 127) / 128))), block(256);
     auto kern = gemm_nt_kernel<T, M_, POOLED>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     kern<<<grid, block, smem, s>>>(a);
 }
 
-void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s) {
-    if (!a.pooled) {
-        if (dtype == 0) launch_one<BF16, 1, false>(a, s); else launch_one<F32, 1, false>(a, s);
-        return;
-    }
-    AECF_DISPATCH_M(a.M, {
-        if (dtype == 0) launch_one<BF16, M_, true>(a, s); else launch_one<F32, M_, true>(a, s);
-    });
+void launch_gemm_nt(int dtype, const GemmNtArgs& a_in, hipStream_t s) {
+    GemmNtArgs a = a_in;
+    static const int dbg = getenv("AECF_GEMM_DEBUG") ? atoi(getenv("AECF_GEMM_DEBUG")) : 0;   // timing experiments only
+    if (!(a.pooled & 1)) a.pooled |= dbg << 8;
+    if (a.pooled & 1) { launch_vproj(dtype, a, s); return; }     // per-modality accumulators (aecf_vproj.hip)
+    if (dtype == 0) launch_one<BF16, 1, false>(a, s); else launch_one<F32, 1, false>(a, s);
 }
 
 }  // namespace aecf

@@ -59,7 +59,7 @@ template <> struct TBlk<F32> {
 };
 
 template <typename T, int M_, bool POOLED, int WJ, int MAXS>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs p) {
     using X = Tr<T>;
     typedef typename X::frag frag;
     constexpr int NR = TBlk<T>::NR, NF = TBlk<T>::NF;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 // heads) is built in registers from ds, as a bf16 hi/lo pair so the small ds values keep ~16 bits.
 // grid (ceil(E/128), 1, S); block 256: wave w owns column tiles 2w, 2w+1 of the 128 k columns.
 template <typename T, int M_>
-__global__ __launch_bounds__(256) void gemm_tn_u_kernel(GemmTnArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_u_kernel(GemmTnArgs p) {
     using X = Tr<T>;
     typedef typename X::frag frag;
     constexpr int NR = TBlk<T>::NR, NF = TBlk<T>::NF;

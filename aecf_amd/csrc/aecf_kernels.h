@@ -54,6 +54,7 @@ struct GemmNtArgs {
     int out_f32;         // store C as float32 regardless of dtype (logits)
 };
 void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
+void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s);   // pooled == 1 path
 
 // ---------------- backward ----------------
 // g_h[b] = W_v,h^T do_h[b] kernels (aecf_bwd_g.hip):

@@ -20,6 +20,21 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * TILE_ROW_BYTES + ((chunk ^ (((row >> 1) ^ (row >> 4)) & 7)) << 4);
 }
 
+// XCD-aware block -> (row panel, column tile) map for [rows x cols] tilings whose column tiles share the row
+// panel's operand: blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2), so the `ncol`
+// column tiles of one row panel get ids b, b+8, b+16, ... -> same XCD, adjacent in time: the panel is fetched from
+// HBM once and re-read from that XCD's L2.  Launch with xcd_grid(npanel, ncol) blocks; returns false for padding ids.
+__host__ __device__ __forceinline__ unsigned int xcd_grid(unsigned int npanel, unsigned int ncol) {
+    return ((npanel + 7u) / 8u) * 8u * ncol;
+}
+__device__ __forceinline__ bool xcd_tile(unsigned int id, unsigned int npanel, unsigned int ncol, unsigned int& panel,
+                                         unsigned int& col) {
+    const unsigned int xcd = id & 7u, slot = id >> 3;
+    panel = (slot / ncol) * 8u + xcd;
+    col = slot % ncol;
+    return panel < npanel;
+}
+
 template <typename T> struct TileK;   // elements of K per 128-byte LDS row
 template <> struct TileK<BF16> { static constexpr int value = 64; };
 template <> struct TileK<F32> { static constexpr int value = 32; };

@@ -1,0 +1,173 @@
+// V projection of the fusion pool, forward (gfx950):
+//     o[b, n] = sum_m a[b, head(n), m] * (x[b,m,:] . W_v[n,:]) + b_v[n]
+// One MFMA accumulator set PER MODALITY over the same staged W_v tile; the softmax weights are applied to the
+// accumulators in the epilogue (M FMAs per output element).  Compared with pooling x before the MFMA this spends
+// M x the matrix flops and saves ~7*H*M*E vector instructions per sample -- the vector ALU, not the matrix
+// pipe, was the bound (profiles/r01_pmc_notes.md).
+//
+// Block = 256 threads = 2x2 waves; block tile 64 samples x 128 columns; wave tile 32 x 64 (2 x 4 MFMA tiles per
+// modality).  LDS: M x-tiles [64][128 B] + one W tile [128][128 B], register-staged one tile ahead.
+#include "aecf_kernels.h"
+#include "aecf_tile.h"
+
+namespace aecf {
+
+template <typename T, int M_>
+__global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
+    using X = Tr<T>;
+    typedef typename X::elem elem;
+    constexpr int ATILE = 64 * TILE_ROW_BYTES;    // 8 KB
+    constexpr int BK = TileK<T>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsA = smem;
+    char* ldsB = smem + M_ * ATILE;
+    float* prl = reinterpret_cast<float*>(ldsB + 128 * TILE_ROW_BYTES);     // probs [64][H][M]
+
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    const int wr = w >> 1, wc = w & 1;
+    unsigned int panel, coltile;
+    if (!xcd_tile(blockIdx.x, (unsigned)((p.R + 63) / 64), (unsigned)((p.N + 127) / 128), panel, coltile)) return;
+    const int64_t r0 = (int64_t)panel * 64;
+    const int n0 = coltile * 128;
+    const int rows_valid = (p.R - r0) >= 64 ? 64 : (int)(p.R - r0);
+    const int cols_valid = (p.N - n0) >= 128 ? 128 : (p.N - n0);
+    const int K = p.K, H = p.H, HM = p.H * M_;
+    const int nkt = K / BK;
+    const int nw0 = n0 + 64 * wc;
+    const int nct = (p.N - nw0) >= 64 ? 4 : ((p.N - nw0) > 0 ? (p.N - nw0) / 16 : 0);
+
+    for (int i = threadIdx.x; i < 64 * HM; i += 256)
+        prl[i] = (i / HM) < rows_valid ? p.probs[r0 * HM + i] : 0.f;
+
+    const char* a_src = reinterpret_cast<const char*>(p.a) + r0 * p.lda * X::BYTES;
+    const char* w_src = reinterpret_cast<const char*>(p.w) + (int64_t)n0 * K * X::BYTES;
+    const int64_t lda_bytes = p.lda * X::BYTES;
+    const int64_t ldw_bytes = (int64_t)K * X::BYTES;
+
+    f32x4 acc[M_][2][4];
+#pragma unroll
+    for (int m = 0; m < M_; ++m)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[m][rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    DirectStage<64, 256> sa[M_];
+    DirectStage<128, 256> sb;
+#pragma unroll
+    for (int m = 0; m < M_; ++m) sa[m].load(a_src + (int64_t)m * K * X::BYTES, lda_bytes, rows_valid);
+    sb.load(w_src, ldw_bytes, cols_valid);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M_; ++m) sa[m].store(ldsA + m * ATILE);
+        sb.store(ldsB);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            const int64_t koff = (int64_t)(kt + 1) * TILE_ROW_BYTES;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) sa[m].load(a_src + (int64_t)m * K * X::BYTES + koff, lda_bytes, rows_valid);
+            sb.load(w_src + koff, ldw_bytes, cols_valid);
+        }
+        if (nct > 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typename X::frag b[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) b[ct] = lds_frag<T>(ldsB, 64 * wc + 16 * ct + r16, 4 * ks + lg);
+#pragma unroll
+                for (int m = 0; m < M_; ++m)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const typename X::frag a = lds_frag<T>(ldsA + m * ATILE, 32 * wr + 16 * rt + r16, 4 * ks + lg);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) acc[m][rt][ct] = X::mma(a, b[ct], acc[m][rt][ct]);
+                    }
+            }
+        }
+    }
+
+    // ---------------- epilogue: weight the per-modality products, add the bias ----------------
+    const elem* bias = reinterpret_cast<const elem*>(p.bias);
+    f32x4 o[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int n = nw0 + 16 * ct + r16;
+        const float bv = (bias && ct < nct) ? X::to_f32(bias[n]) : 0.f;
+        int h = (nw0 + 16 * ct) / p.hd;
+        h = h < H ? h : H - 1;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* pr = prl + (32 * wr + 16 * rt + 4 * lg + r) * HM + h * M_;
+                float v = bv;
+#pragma unroll
+                for (int m = 0; m < M_; ++m) v = fmaf(pr[m], acc[m][rt][ct][r], v);
+                o[rt][ct][r] = v;
+            }
+    }
+    if (X::BYTES == 2) {
+        __syncthreads();
+        char* cl = smem;                      // [64][128] bf16 image, 256-byte rows
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const bool odd = r16 & 1;
+                const float send0 = odd ? o[rt][ct][0] : o[rt][ct][2], send1 = odd ? o[rt][ct][1] : o[rt][ct][3];
+                const float got0 = __shfl_xor(send0, 1, 64), got1 = __shfl_xor(send1, 1, 64);
+                const int col = 64 * wc + 16 * ct + (r16 & ~1);
+                const int rowb = 32 * wr + 16 * rt + 4 * lg + (odd ? 2 : 0);
+                const unsigned int d0 = odd ? pack_bf16x2(got0, o[rt][ct][2]) : pack_bf16x2(o[rt][ct][0], got0);
+                const unsigned int d1 = odd ? pack_bf16x2(got1, o[rt][ct][3]) : pack_bf16x2(o[rt][ct][1], got1);
+                *reinterpret_cast<unsigned int*>(cl + (rowb + 0) * 256 + col * 2) = d0;
+                *reinterpret_cast<unsigned int*>(cl + (rowb + 1) * 256 + col * 2) = d1;
+            }
+        __syncthreads();
+        char* c = reinterpret_cast<char*>(p.c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = threadIdx.x + 256 * i;          // 1024 chunks of 16 B: row = ch / 16, chunk = ch % 16
+            const int row = ch >> 4, cc = ch & 15;
+            if (row < rows_valid && cc * 8 < cols_valid)
+                *reinterpret_cast<u32x4*>(c + ((r0 + row) * p.N + n0) * 2 + cc * 16) =
+                    *reinterpret_cast<const u32x4*>(cl + row * 256 + cc * 16);
+        }
+    } else {
+        elem* c = reinterpret_cast<elem*>(p.c);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            if (ct < nct) {
+                const int n = nw0 + 16 * ct + r16;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = r0 + 32 * wr + 16 * rt + 4 * lg + r;
+                        if (row < p.R) c[row * p.N + n] = X::from_f32(o[rt][ct][r]);
+                    }
+            }
+        }
+    }
+}
+
+template <typename T, int M_>
+static void launch_one(const GemmNtArgs& a, hipStream_t s) {
+    size_t smem = (size_t)M_ * 64 * TILE_ROW_BYTES + (size_t)128 * TILE_ROW_BYTES + (size_t)64 * a.H * M_ * sizeof(float);
+    if (smem < 64 * 256) smem = 64 * 256;     // the bf16 output image
+    dim3 grid(xcd_grid((unsigned)((a.R + 63) / 64), (unsigned)((a.N + 127) / 128))), block(256);
+    auto kern = vproj_modal_kernel<T, M_>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a);
+}
+
+void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s) {
+    AECF_DISPATCH_M(a.M, {
+        if (dtype == 0) launch_one<BF16, M_>(a, s); else launch_one<F32, M_>(a, s);
+    });
+}
+
+}  // namespace aecf
