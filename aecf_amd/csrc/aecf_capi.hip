@@ -32,8 +32,8 @@ FwdWs fwd_layout(const aecf_pool_desc* d) {
 
 struct BwdWs {
     size_t qs, a_f32, a_hi, a_lo, wvt, wot, dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, dq_part, total;
-    int splits;
-    int64_t rows_per_split;
+    int splits, u_splits;
+    int64_t rows_per_split, u_rows_per_split;
 };
 BwdWs bwd_layout(const aecf_pool_desc* d) {
     BwdWs w;
@@ -49,6 +49,17 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     S = (int)((B + rps - 1) / rps);
     w.splits = S;
     w.rows_per_split = rps;
+    {   // u = ds^T x: [16, E] per split -> ~1024 blocks
+        const int kt = (int)((E + 127) / 128);
+        int Su = (1024 + kt - 1) / kt;
+        const int64_t max_su = (int64_t)((B + 63) / 64);
+        if (Su > max_su) Su = (int)max_su;
+        if (Su < 1) Su = 1;
+        int64_t urps = (int64_t)((B + Su - 1) / Su);
+        urps = (urps + 63) / 64 * 64;
+        w.u_splits = (int)((B + urps - 1) / urps);
+        w.u_rows_per_split = urps;
+    }
     size_t off = 0;
     w.qs = off;     off = align_up(off + E * 4);
     w.a_f32 = off;  off = align_up(off + HPAD * E * 4);
@@ -62,7 +73,7 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     w.slab_v = off; off = align_up(off + (size_t)S * E * E * 4);
     w.cs_o = off;   off = align_up(off + (size_t)S * E * 4);
     w.cs_v = off;   off = align_up(off + (size_t)S * E * 4);
-    w.u_slab = off; off = align_up(off + (size_t)S * HPAD * E * 4);
+    w.u_slab = off; off = align_up(off + (size_t)w.u_splits * HPAD * E * 4);
     w.u = off;      off = align_up(off + HPAD * E * 4);
     w.dqp = off;    off = align_up(off + E * 4);
     w.dq_part = off; off = align_up(off + (E / 64) * E * 4);
@@ -231,6 +242,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     t1.lhs = a->dy; t1.rhs = a->saved_o; t1.probs = nullptr; t1.dsbuf = nullptr; t1.out = (float*)(ws + L.slab_o);
     t1.colsum = (float*)(ws + L.cs_o); t1.u = nullptr; t1.B = B; t1.M = 1; t1.E = E; t1.H = H; t1.hd = hd;
     t1.Ej = 0; t1.splits = L.splits; t1.rows_per_split = L.rows_per_split; t1.pooled = 0;
+    t1.u_splits = 0; t1.u_rows_per_split = 0;
     launch_gemm_tn(d->dtype, t1, s);
     mark(ev, 3, s);
 
@@ -248,11 +260,13 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     t2.lhs = dobuf; t2.rhs = a->x; t2.probs = a->saved_probs; t2.dsbuf = dsbuf; t2.out = (float*)(ws + L.slab_v);
     t2.colsum = (float*)(ws + L.cs_v); t2.u = (float*)(ws + L.u_slab); t2.B = B; t2.M = M; t2.E = E; t2.H = H;
     t2.hd = hd; t2.Ej = 0; t2.splits = L.splits; t2.rows_per_split = L.rows_per_split; t2.pooled = 1;
+    t2.u_splits = L.u_splits; t2.u_rows_per_split = L.u_rows_per_split;
     launch_gemm_tn(d->dtype, t2, s);
     mark(ev, 6, s);
 
     ReduceSegs rs;
-    rs.splits = L.splits;
+    for (int i = 0; i < ReduceSegs::N; ++i) rs.splits[i] = L.splits;
+    rs.splits[4] = L.u_splits;
     rs.src[0] = (const float*)(ws + L.slab_o); rs.dst[0] = a->dw_out;                    rs.n[0] = (int64_t)E * E;
     rs.src[1] = (const float*)(ws + L.cs_o);   rs.dst[1] = a->db_out;                    rs.n[1] = E;
     rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = a->dw_in + (size_t)2 * E * E; rs.n[2] = (int64_t)E * E;
@@ -377,7 +391,7 @@ int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, 
     launch_gemm_nt(dtype, g2, s);
     GemmTnArgs t;        // dk = G^T q   (reduction over the local rows)
     t.lhs = G; t.rhs = q; t.probs = nullptr; t.dsbuf = nullptr; t.out = dk; t.colsum = nullptr; t.u = nullptr;
-    t.B = rows; t.M = 1; t.E = d; t.H = 1; t.hd = d; t.Ej = (int)cols; t.splits = 1;
+    t.B = rows; t.M = 1; t.E = d; t.H = 1; t.hd = d; t.Ej = (int)cols; t.splits = 1; t.u_splits = 0; t.u_rows_per_split = 0;
     t.rows_per_split = (rows + 63) / 64 * 64; t.pooled = 0;
     launch_gemm_tn(dtype, t, s);
     return launch_status();

@@ -10,14 +10,21 @@
 
 namespace aecf {
 
+// 8 consecutive lanes per output element: lane g sums the splits k = g, g+8, ... (coalesced across elements is not
+// needed: slabs are [split][element], so the 8 lanes read 8 different slabs at the same offset), then a fixed-order
+// butterfly adds the 8 partials -> deterministic, and short loops even for hundreds of splits.
 __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs r) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int g = threadIdx.x & 7;
 #pragma unroll
     for (int s = 0; s < ReduceSegs::N; ++s) {
         if (i < r.n[s]) {
             float a = 0.f;
-            for (int k = 0; k < r.splits; ++k) a += r.src[s][(int64_t)k * r.n[s] + i];
-            r.dst[s][i] = a;
+            for (int k = g; k < r.splits[s]; k += 8) a += r.src[s][(int64_t)k * r.n[s] + i];
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            if (g == 0) r.dst[s][i] = a;
             return;
         }
         i -= r.n[s];
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void fin_dquery_kernel(FinalizeArgs p) {
 void launch_reduce_segments(const ReduceSegs& r, hipStream_t s) {
     int64_t total = 0;
     for (int i = 0; i < ReduceSegs::N; ++i) total += r.n[i];
-    reduce_segments_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(r);
+    reduce_segments_kernel<<<dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, s>>>(r);
 }
 
 void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s) {

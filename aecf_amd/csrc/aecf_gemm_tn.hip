@@ -80,8 +80,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs p) {
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
 
     constexpr bool u_block = false;                               // (u has its own kernel below)
-    const int j0 = u_block ? 0 : blockIdx.y * BJ, k0 = blockIdx.x * 128;
-    const int split = blockIdx.z;
+    // 1-D grid: the (j,k) tiles of one batch split share its lhs/rhs rows -> keep them on one XCD (aecf_tile.h)
+    const unsigned int nK = (unsigned)((E + 127) / 128), nJt = (unsigned)((EJ + BJ - 1) / BJ);
+    unsigned int split_u, tile_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)p.splits, nK * nJt, split_u, tile_u)) return;
+    const int kt_idx = (int)(tile_u % nK), jt_idx = (int)(tile_u / nK);
+    const int j0 = jt_idx * BJ, k0 = kt_idx * 128;
+    const int split = (int)split_u;
     const int64_t rbeg = (int64_t)split * p.rows_per_split;
     const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
     const int jrows = (EJ - j0) >= BJ ? BJ : (EJ - j0);    // valid j rows / k cols of this block (multiples of 64)
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs p) {
                 }
     }
     // column sums: thread (fg, bg) holds partial sums of its NF features over its batch rows; fold the bg in order
-    if (blockIdx.x == 0 && p.colsum) {
+    if (kt_idx == 0 && p.colsum) {
         __syncthreads();
         if (bgl < BG) {
 #pragma unroll
@@ -278,8 +283,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_u_kernel(GemmTnArgs p) {
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     const int k0 = blockIdx.x * 128;
     const int split = blockIdx.z;
-    const int64_t rbeg = (int64_t)split * p.rows_per_split;
-    const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
+    const int64_t rbeg = (int64_t)split * p.u_rows_per_split;
+    const int64_t rend = (rbeg + p.u_rows_per_split) < p.B ? (rbeg + p.u_rows_per_split) : p.B;
     const int kcols = (E - k0) >= 128 ? 128 : (E - k0);
     const int fgr = threadIdx.x % FG, bgr = threadIdx.x / FG;
     const bool r_on = NF * fgr < kcols;
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_u_kernel(GemmTnArgs p) {
 template <typename T, int M_>
 static void launch_u(const GemmTnArgs& a, hipStream_t s) {
     const size_t smem = (size_t)M_ * 128 * TILE_ROW_BYTES;
-    dim3 grid((a.E + 127) / 128, 1, a.splits), block(256);
+    dim3 grid((a.E + 127) / 128, 1, a.u_splits), block(256);
     auto kern = gemm_tn_u_kernel<T, M_>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -364,7 +369,7 @@ static void launch_one(const GemmTnArgs& a, hipStream_t s) {
     if (POOLED) smem += (size_t)BBT * MAXS * M_ * sizeof(float);
     smem += (size_t)16 * BJ * sizeof(float);
     const int nJ = ((a.Ej > 0 ? a.Ej : a.E) + BJ - 1) / BJ;
-    dim3 grid((a.E + 127) / 128, nJ, a.splits), block(256);
+    dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)(((a.E + 127) / 128) * nJ))), block(256);
     auto kern = gemm_tn_kernel<T, M_, POOLED, WJ, MAXS>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -95,6 +95,8 @@ struct GemmTnArgs {
     int Ej;               // lhs feature count when it differs from E (rectangular, non-pooled); 0 = E
     int splits;           // S
     int64_t rows_per_split;   // multiple of 32
+    int u_splits;             // the u kernel has its own (finer) batch split: tiny output, needs more blocks
+    int64_t u_rows_per_split;
     int pooled;
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
@@ -105,7 +107,7 @@ struct ReduceSegs {
     const float* src[N];
     float* dst[N];
     int64_t n[N];
-    int splits;
+    int splits[N];
 };
 void launch_reduce_segments(const ReduceSegs& r, hipStream_t s);
 

@@ -178,11 +178,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    dev_index = local % max(ndev, 1)          # rehearsal on a 1-GPU box: several ranks may share device 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+        # RCCL ("nccl") over xGMI is the real path; AECF_DIST_BACKEND=gloo only rehearses the N>1 code on one GPU
+        backend = os.environ.get("AECF_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     cfg = CONFIGS[args.config]
     B, M, E, H, dtype, p = cfg
     pool, query, x, dy = make_inputs(cfg, device)
