@@ -122,7 +122,7 @@ def stage_model(cfg):
     s = 2 if dtype == torch.bfloat16 else 4
     return {
         "fwd.gate":    dict(bytes=s * M * E, flops=2 * M * E * 16 * (2 if s == 2 else 1)),
-        "fwd.vproj":   dict(bytes=s * (M + 1) * E, flops=2 * E * E),
+        "fwd.vproj":   dict(bytes=s * (M + 1) * E, flops=2 * M * E * E),      # one accumulator set per modality
         "fwd.outproj": dict(bytes=s * 2 * E, flops=2 * E * E),
         "bwd.dout":    dict(bytes=s * 2 * E, flops=2 * E * E),
         "bwd.dw_out":  dict(bytes=s * 2 * E, flops=2 * E * E),
@@ -233,15 +233,22 @@ def main():
         stages = st.mean_ms()
         model = stage_model(cfg)
         dom = max((k for k in stages if k in model), key=lambda k: stages[k])
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # corrected as MI355X_MICROARCH.md prescribes); null when no counter pass exists for this config
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"r01_v2_{args.config}_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f)["bytes_per_launch"].get(dom)
         t_s = stages[dom] * 1e-3
         gbs = model[dom]["bytes"] * B / t_s / 1e9
         tfl = model[dom]["flops"] * B / t_s / 1e12
         if gbs / HBM_PEAK_GBS >= tfl / MFMA_PEAK_TFLOPS:
             roofline = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                            traffic=None, kernel=dom, kernel_ms=stages[dom])
+                            traffic=traffic, kernel=dom, kernel_ms=stages[dom])
         else:
             roofline = dict(bound="mfma", achieved=tfl, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=tfl / MFMA_PEAK_TFLOPS, traffic=None, kernel=dom, kernel_ms=stages[dom])
+                            frac=tfl / MFMA_PEAK_TFLOPS, traffic=traffic, kernel=dom, kernel_ms=stages[dom])
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
