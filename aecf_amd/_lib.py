@@ -46,7 +46,7 @@ class PoolFwdArgs(Structure):
         ("w_out", c_void_p), ("b_out", c_void_p), ("key_padding_mask", c_void_p),
         ("uniforms", c_void_p), ("y", c_void_p), ("attn_w", c_void_p), ("masked_w", c_void_p),
         ("entropy", c_void_p), ("mask_rate", c_void_p), ("saved_probs", c_void_p),
-        ("saved_o", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("saved_o", c_void_p), ("saved_v", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
     ]
 
@@ -55,7 +55,8 @@ class PoolBwdArgs(Structure):
     _fields_ = [
         ("x", c_void_p), ("query", c_void_p), ("w_in", c_void_p), ("b_in", c_void_p),
         ("w_out", c_void_p), ("dy", c_void_p), ("d_attn_w", c_void_p), ("d_entropy", c_void_p),
-        ("attn_w", c_void_p), ("saved_probs", c_void_p), ("saved_o", c_void_p), ("dx", c_void_p),
+        ("attn_w", c_void_p), ("saved_probs", c_void_p), ("saved_o", c_void_p), ("saved_v", c_void_p),
+        ("dx", c_void_p),
         ("dquery", c_void_p), ("dw_in", c_void_p), ("db_in", c_void_p), ("dw_out", c_void_p),
         ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),

@@ -187,13 +187,13 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     v.a = a->x; v.w = (const char*)a->w_in + (size_t)2 * E * E * es;
     v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
     v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
-    v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = 0;
+    v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = 0; v.v_out = a->saved_v;
     launch_gemm_nt(d->dtype, v, s);
     mark(ev, 3, s);
 
     GemmNtArgs y;
     y.a = o; y.w = a->w_out; y.bias = a->b_out; y.c = a->y; y.probs = nullptr; y.R = d->batch; y.N = E; y.K = E;
-    y.lda = E; y.M = 1; y.H = H; y.hd = hd; y.pooled = 0; y.out_f32 = 0;
+    y.lda = E; y.M = 1; y.H = H; y.hd = hd; y.pooled = 0; y.out_f32 = 0; y.v_out = nullptr;
     launch_gemm_nt(d->dtype, y, s);
     mark(ev, 4, s);
     return launch_status();
@@ -233,7 +233,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     // do = dy W_o   (NT GEMM against W_o^T)
     GemmNtArgs g;
     g.a = a->dy; g.w = wot; g.bias = nullptr; g.c = dobuf; g.probs = nullptr; g.R = B; g.N = E; g.K = E; g.lda = E;
-    g.M = 1; g.H = H; g.hd = hd; g.pooled = 0; g.out_f32 = 0;
+    g.M = 1; g.H = H; g.hd = hd; g.pooled = 0; g.out_f32 = 0; g.v_out = nullptr;
     launch_gemm_nt(d->dtype, g, s);
     mark(ev, 2, s);
 
@@ -250,7 +250,8 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     g2.x = a->x; g2.dobuf = dobuf; g2.wvt = wvt; g2.probs = a->saved_probs; g2.d_attn_w = a->d_attn_w;
     g2.d_entropy = a->d_entropy; g2.attn_w = a->attn_w; g2.dsbuf = dsbuf; g2.a_f32 = a_f32; g2.dx = a->dx;
     g2.B = B; g2.M = M; g2.E = E; g2.H = H; g2.hd = hd; g2.log_M = (float)log((double)M);
-    launch_bwd_g(d->dtype, g2, false, s);
+    if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
+        launch_bwd_g(d->dtype, g2, false, s);      // no saved V (or unsupported head size): recompute W_v^T do per head
     mark(ev, 4, s);
     launch_bwd_g(d->dtype, g2, true, s);
     mark(ev, 5, s);
@@ -381,13 +382,13 @@ int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, 
 
     GemmNtArgs g1;       // S = q k^T  (float32 logits before the temperature)
     g1.a = q; g1.w = k; g1.bias = nullptr; g1.c = S; g1.probs = nullptr; g1.R = rows; g1.N = (int)cols; g1.K = d;
-    g1.lda = d; g1.M = 1; g1.H = 1; g1.hd = d; g1.pooled = 0; g1.out_f32 = 1;
+    g1.lda = d; g1.M = 1; g1.H = 1; g1.hd = d; g1.pooled = 0; g1.out_f32 = 1; g1.v_out = nullptr;
     launch_gemm_nt(dtype, g1, s);
     launch_nce_rows(dtype, rows, cols, row_offset, 1.0f / temperature, coef, S, G, loss_rows, s);
     launch_transpose_rect(dtype, k, kT, cols, d, s);
     GemmNtArgs g2;       // dq = G k
     g2.a = G; g2.w = kT; g2.bias = nullptr; g2.c = dq; g2.probs = nullptr; g2.R = rows; g2.N = d; g2.K = (int)cols;
-    g2.lda = cols; g2.M = 1; g2.H = 1; g2.hd = d; g2.pooled = 0; g2.out_f32 = 1;
+    g2.lda = cols; g2.M = 1; g2.H = 1; g2.hd = d; g2.pooled = 0; g2.out_f32 = 1; g2.v_out = nullptr;
     launch_gemm_nt(dtype, g2, s);
     GemmTnArgs t;        // dk = G^T q   (reduction over the local rows)
     t.lhs = G; t.rhs = q; t.probs = nullptr; t.dsbuf = nullptr; t.out = dk; t.colsum = nullptr; t.u = nullptr;

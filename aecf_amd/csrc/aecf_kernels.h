@@ -52,6 +52,7 @@ struct GemmNtArgs {
     int M, H, hd;
     int pooled;
     int out_f32;         // store C as float32 regardless of dtype (logits)
+    void* v_out;         // pooled only: [R,M,N] dtype, the per-modality products W x_m + bias (or null)
 };
 void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
 void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s);   // pooled == 1 path
@@ -76,6 +77,9 @@ struct BwdGArgs {
     float log_M;
 };
 void launch_bwd_g(int dtype, const BwdGArgs& a, bool dx, hipStream_t s);
+// score gradient from the saved value projections: da[b,h,m] = do_h[b] . V_h[b,m]  (memory-bound, one wave per sample)
+// returns false when the head size is not supported by this kernel (caller falls back to launch_bwd_g(dx = false))
+bool launch_dscore_v(int dtype, const BwdGArgs& a, const void* saved_v, hipStream_t s);
 
 // out[split][j][k] = sum_{b in split} lhs[b][j] * rhs(b,k)        (f32 partial slabs, deterministic)
 //   pooled == 0: rhs(b,k) = rhs[b*E + k]

@@ -108,45 +108,68 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
                 o[rt][ct][r] = v;
             }
     }
+    // ---- stores.  bf16: ONE LDS pass -- image [64 rows][1 + M slots][128 cols] (slot 0 = o, slot 1+m = V_m, the
+    //      per-modality products W x_m + bias kept for the backward score gradient), then full-row 16-byte stores.
     if (X::BYTES == 2) {
+        const int nslot = p.v_out ? M_ + 1 : 1;
+        const int pitch = nslot * 256;
         __syncthreads();
-        char* cl = smem;                      // [64][128] bf16 image, 256-byte rows
+        char* cl = smem;
+        auto put = [&](int slot, int rt, int ct, float v0, float v1, float v2, float v3) {
+            const bool odd = r16 & 1;
+            const float send0 = odd ? v0 : v2, send1 = odd ? v1 : v3;
+            const float got0 = __shfl_xor(send0, 1, 64), got1 = __shfl_xor(send1, 1, 64);
+            const int col = 64 * wc + 16 * ct + (r16 & ~1);
+            const int rowb = 32 * wr + 16 * rt + 4 * lg + (odd ? 2 : 0);
+            char* base = cl + slot * 256 + col * 2;
+            *reinterpret_cast<unsigned int*>(base + (rowb + 0) * pitch) = odd ? pack_bf16x2(got0, v2) : pack_bf16x2(v0, got0);
+            *reinterpret_cast<unsigned int*>(base + (rowb + 1) * pitch) = odd ? pack_bf16x2(got1, v3) : pack_bf16x2(v1, got1);
+        };
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                const bool odd = r16 & 1;
-                const float send0 = odd ? o[rt][ct][0] : o[rt][ct][2], send1 = odd ? o[rt][ct][1] : o[rt][ct][3];
-                const float got0 = __shfl_xor(send0, 1, 64), got1 = __shfl_xor(send1, 1, 64);
-                const int col = 64 * wc + 16 * ct + (r16 & ~1);
-                const int rowb = 32 * wr + 16 * rt + 4 * lg + (odd ? 2 : 0);
-                const unsigned int d0 = odd ? pack_bf16x2(got0, o[rt][ct][2]) : pack_bf16x2(o[rt][ct][0], got0);
-                const unsigned int d1 = odd ? pack_bf16x2(got1, o[rt][ct][3]) : pack_bf16x2(o[rt][ct][1], got1);
-                *reinterpret_cast<unsigned int*>(cl + (rowb + 0) * 256 + col * 2) = d0;
-                *reinterpret_cast<unsigned int*>(cl + (rowb + 1) * 256 + col * 2) = d1;
+                put(0, rt, ct, o[rt][ct][0], o[rt][ct][1], o[rt][ct][2], o[rt][ct][3]);
+                if (p.v_out) {
+                    const int n = nw0 + 16 * ct + r16;
+                    const float bv = (bias && ct < nct) ? X::to_f32(bias[n]) : 0.f;
+#pragma unroll
+                    for (int m = 0; m < M_; ++m)
+                        put(1 + m, rt, ct, acc[m][rt][ct][0] + bv, acc[m][rt][ct][1] + bv, acc[m][rt][ct][2] + bv,
+                            acc[m][rt][ct][3] + bv);
+                }
             }
         __syncthreads();
         char* c = reinterpret_cast<char*>(p.c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = threadIdx.x + 256 * i;          // 1024 chunks of 16 B: row = ch / 16, chunk = ch % 16
-            const int row = ch >> 4, cc = ch & 15;
-            if (row < rows_valid && cc * 8 < cols_valid)
-                *reinterpret_cast<u32x4*>(c + ((r0 + row) * p.N + n0) * 2 + cc * 16) =
-                    *reinterpret_cast<const u32x4*>(cl + row * 256 + cc * 16);
+        char* vo = reinterpret_cast<char*>(p.v_out);
+        for (int i = threadIdx.x; i < 64 * 16 * nslot; i += 256) {      // 16-byte chunks: (row, slot, chunk)
+            const int cc = i & 15, slot = (i >> 4) % nslot, row = (i >> 4) / nslot;
+            if (row < rows_valid && cc * 8 < cols_valid) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(cl + row * pitch + slot * 256 + cc * 16);
+                if (slot == 0) *reinterpret_cast<u32x4*>(c + ((r0 + row) * p.N + n0) * 2 + cc * 16) = v;
+                else *reinterpret_cast<u32x4*>(vo + (((r0 + row) * M_ + (slot - 1)) * p.N + n0) * 2 + cc * 16) = v;
+            }
         }
     } else {
         elem* c = reinterpret_cast<elem*>(p.c);
+        elem* vo = reinterpret_cast<elem*>(p.v_out);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             if (ct < nct) {
                 const int n = nw0 + 16 * ct + r16;
+                const float bv = bias ? X::to_f32(bias[n]) : 0.f;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t row = r0 + 32 * wr + 16 * rt + 4 * lg + r;
-                        if (row < p.R) c[row * p.N + n] = X::from_f32(o[rt][ct][r]);
+                        if (row < p.R) {
+                            c[row * p.N + n] = X::from_f32(o[rt][ct][r]);
+                            if (vo) {
+#pragma unroll
+                                for (int m = 0; m < M_; ++m) vo[(row * M_ + m) * p.N + n] = X::from_f32(acc[m][rt][ct][r] + bv);
+                            }
+                        }
                     }
             }
         }
@@ -156,7 +179,8 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
 template <typename T, int M_>
 static void launch_one(const GemmNtArgs& a, hipStream_t s) {
     size_t smem = (size_t)M_ * 64 * TILE_ROW_BYTES + (size_t)128 * TILE_ROW_BYTES + (size_t)64 * a.H * M_ * sizeof(float);
-    if (smem < 64 * 256) smem = 64 * 256;     // the bf16 output image
+    const size_t image = (size_t)64 * 256 * (a.v_out ? M_ + 1 : 1);     // the bf16 output image(s)
+    if (smem < image) smem = image;
     dim3 grid(xcd_grid((unsigned)((a.R + 63) / 64), (unsigned)((a.N + 127) / 128))), block(256);
     auto kern = vproj_modal_kernel<T, M_>;
     if (smem > 64 * 1024)

@@ -79,6 +79,9 @@ class _PoolFunction(torch.autograd.Function):
         attn_w = torch.empty(B, M, dtype=torch.float32, device=dev)
         probs = torch.empty(B, num_heads, M, dtype=torch.float32, device=dev)
         saved_o = torch.empty(B, E, dtype=dt, device=dev)
+        # per-modality value projections, kept only when a backward will follow (B*M*E elements)
+        need_bwd = any(t is not None and t.requires_grad for t in (x, q, w_in, b_in, w_out, b_out))
+        saved_v = torch.empty(B, M, E, dtype=dt, device=dev) if need_bwd else None
         if mask_mode != 0:
             masked_w = torch.empty(B, M, dtype=torch.float32, device=dev)
             entropy = torch.empty(B, dtype=torch.float32, device=dev)
@@ -90,10 +93,10 @@ class _PoolFunction(torch.autograd.Function):
         args = _lib.PoolFwdArgs(
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(b_out_c), _ptr(kpm),
             _ptr(uniforms), _ptr(y), _ptr(attn_w), _ptr(masked_w), _ptr(entropy), _ptr(mask_rate),
-            _ptr(probs), _ptr(saved_o), _ptr(ws), ws_bytes,
+            _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(ws), ws_bytes,
             None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd))
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
-        ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w)
+        ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v)
         ctx.desc = desc
         ctx.q_shape = q.shape
         ctx.param_dtypes = (q.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
@@ -109,7 +112,7 @@ class _PoolFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, d_attn_w, _d_masked, d_entropy, _d_rate):
         lib = _lib.load()
-        xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w = ctx.saved_tensors
+        xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v = ctx.saved_tensors
         desc = ctx.desc
         B, M, E = xc.shape
         dev = xc.device
@@ -129,7 +132,7 @@ class _PoolFunction(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolBwdArgs(
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(dy_c), _ptr(daw), _ptr(dent),
-            _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
+            _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
             _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes,
             None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd))
         _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")

@@ -80,6 +80,8 @@ typedef struct aecf_pool_fwd_args {
     float* mask_rate;            /* [B]   or NULL                                        */
     float* saved_probs;          /* [B,H,M] per-head softmax, saved for backward         */
     void* saved_o;               /* [B,E] dtype: pre-out-projection heads, saved for backward (or NULL) */
+    void* saved_v;               /* [B,M,E] dtype: per-modality value projections W_v x + b_v, saved so that the
+                                  * backward score gradient is a memory-bound dot instead of a recompute (or NULL) */
     void* workspace;
     size_t workspace_bytes;
     /* optional profiling hook: AECF_FWD_STAGES+1 hipEvent_t handles (caller-created); event[0] is recorded
@@ -100,6 +102,7 @@ typedef struct aecf_pool_bwd_args {
     const float* attn_w;         /* [B,M] forward output (needed with d_entropy)         */
     const float* saved_probs;    /* [B,H,M]                                              */
     const void* saved_o;         /* [B,E]                                                */
+    const void* saved_v;         /* [B,M,E] or NULL (NULL: the score gradient recomputes W_v^T do per head)  */
     void* dx;                    /* [B,M,E] dtype                                        */
     float* dquery;               /* [E]                                                  */
     float* dw_in;                /* [3E,E]                                               */
