@@ -1,0 +1,116 @@
+"""GPU parity sweep over the shapes the kernels template on: modality count 1..8, head count 1..16, embed sizes that
+exercise ragged tiles (64, 192, 768, 1024), head sizes 16..256, batch sizes that are not multiples of any tile,
+with and without key_padding_mask / gradient on the attention weights.  Checked against the CPU oracle."""
+import pytest
+import torch
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+# (B, M, E, H)
+SHAPES = [
+    (1, 1, 64, 1),        # a single sample, a single modality (L <= 1 early-out of the masking)
+    (37, 2, 64, 2),
+    (100, 5, 128, 4),
+    (77, 8, 128, 2),      # M = 8: the largest instantiation
+    (130, 3, 192, 2),     # E = 192: ragged 128-wide tiles, head_dim 96
+    (65, 2, 768, 8),      # BASELINE configs[2] shape (head_dim 96 spans tile boundaries)
+    (70, 4, 1024, 8),     # BASELINE configs[4] shape
+    (129, 3, 256, 16),    # 16 heads (head_dim 16: fp32 only)
+    (200, 3, 512, 2),     # head_dim 256
+    (513, 6, 64, 1),
+]
+
+
+def _case(B, M, E, H, dtype, kpm, seed):
+    import aecf_amd
+    from aecf_amd import layer
+    from oracle import aecf_oracle as O
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    bf = lambda t_: t_.to(torch.bfloat16).float()
+    x = bf(rnd(B, M, E) * torch.linspace(0.5, 2.0, M).view(1, M, 1))
+    q = bf(rnd(1, 1, E) * 0.4)
+    w_in = bf(rnd(3 * E, E) / E ** 0.5)
+    b_in = bf(rnd(3 * E) * 0.05)
+    w_out = bf(rnd(E, E) / E ** 0.5)
+    b_out = bf(rnd(E) * 0.05)
+    dy = bf(rnd(B, 1, E))
+    dw = rnd(B, 1, M)
+    U = torch.rand(B, 1, M, generator=g)
+    mask = None
+    if kpm and M > 1:
+        mask = torch.rand(B, M, generator=g) < 0.3
+        mask[:, 0] = False
+
+    pool = aecf_amd.MultimodalAttentionPool(E, num_heads=H, curriculum_masking=aecf_amd.CurriculumMasking(0.3))
+    with torch.no_grad():
+        pool.attention.in_proj_weight.copy_(w_in)
+        pool.attention.in_proj_bias.copy_(b_in)
+        pool.attention.out_proj.weight.copy_(w_out)
+        pool.attention.out_proj.bias.copy_(b_out)
+    pool = pool.to(dev).train()                       # fp32 master parameters; activations in `dtype`
+    xd = x.to(dev, dtype).requires_grad_(True)
+    qd = q.to(dev).requires_grad_(True)
+    layer._uniforms_override = U
+    out, info = pool(qd.to(dtype).expand(B, -1, -1) if dtype != torch.float32 else qd.expand(B, -1, -1), xd,
+                     key_padding_mask=None if mask is None else mask.to(dev), return_info=True)
+    layer._uniforms_override = None
+    loss = (out.float() * dy.to(dev)).sum() + (info["attention_weights"].float() * dw.to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    qe = q.expand(B, -1, -1)
+    f = O.mha_forward(qe, x, x, w_in, b_in, w_out, b_out, H, mask)
+    b = O.mha_backward(qe, x, x, w_in, b_in, w_out, H, f, dy, dw)
+    c = lambda t_: t_.detach().float().cpu()
+    a = pool.attention
+    got = dict(y=c(out), wbar=c(info["attention_weights"]), dx=c(xd.grad), dw_in=c(a.in_proj_weight.grad),
+               db_in=c(a.in_proj_bias.grad), dw_out=c(a.out_proj.weight.grad), db_out=c(a.out_proj.bias.grad),
+               dq=c(qd.grad))
+    want = dict(y=f["y"], wbar=f["wbar"], dx=b["dkey"] + b["dvalue"], dw_in=b["dw_in"], db_in=b["db_in"],
+                dw_out=b["dw_out"], db_out=b["db_out"], dq=b["dquery"].sum(0, keepdim=True))
+    errs = {k: rel_err(got[k], want[k]) for k in got}
+    # masking of the kernel's own weights (the oracle on the kernel's float32 weights is the contract)
+    if M > 1:
+        m = O.curriculum_mask_train(c(info["attention_weights"]) if dtype == torch.float32 else f["wbar"], U, 0.3)
+        agree = float(((c(info["masked_attention_weights"]) != 0) == (m["masked"] != 0)).float().mean())
+    else:
+        agree = 1.0
+        assert float(info["entropy"].abs().max()) == 0.0 and float(info["mask_rate"].abs().max()) == 0.0
+    return errs, agree
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"B{b}_M{m}_E{e}_H{h}" for b, m, e, h in SHAPES])
+@pytest.mark.parametrize("kpm", [False, True], ids=["nomask", "kpm"])
+def test_shapes_fp32(shape, kpm):
+    B, M, E, H = shape
+    errs, agree = _case(B, M, E, H, torch.float32, kpm, seed=B + M + E + H)
+    for k, e in errs.items():
+        assert e < 1e-5, (shape, k, e)
+    assert agree == 1.0
+
+
+@pytest.mark.parametrize("shape", [s for s in SHAPES if (s[2] // s[3]) % 32 == 0],
+                         ids=[f"B{b}_M{m}_E{e}_H{h}" for b, m, e, h in SHAPES if (e // h) % 32 == 0])
+def test_shapes_bf16(shape):
+    B, M, E, H = shape
+    errs, agree = _case(B, M, E, H, torch.bfloat16, False, seed=B + M + E + H + 1)
+    tol = 1e-3 + 2.0 ** -8
+    for k in ("y", "wbar", "dx"):
+        assert errs[k] < tol, (shape, k, errs[k])
+    for k in ("dw_in", "db_in", "dw_out", "db_out", "dq"):          # float32 outputs of the bf16 kernels
+        assert errs[k] < 4e-3, (shape, k, errs[k])
+    assert agree > 0.99
+
+
+def test_bf16_head_dim_16_is_refused():
+    import aecf_amd
+    dev = torch.device("cuda:0")
+    pool = aecf_amd.MultimodalAttentionPool(256, num_heads=16).to(dev, torch.bfloat16)
+    x = torch.randn(8, 3, 256, device=dev, dtype=torch.bfloat16)
+    q = torch.randn(1, 1, 256, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="not supported"):
+        pool(q.expand(8, -1, -1), x)
