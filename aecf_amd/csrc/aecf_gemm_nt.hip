@@ -76,60 +76,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    DirectStage<128, 256> sa[NA], sb;
-#pragma unroll
-    for (int m = 0; m < NA; ++m) sa[m].load(a_src + (int64_t)m * K * X::BYTES, lda_bytes, rows_valid);
-    sb.load(w_src, ldw_bytes, cols_valid);
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();                       // everyone finished reading the previous tile
-#pragma unroll
-        for (int m = 0; m < NA; ++m) sa[m].store(ldsA + m * TILE);
-        sb.store(ldsB);
-        __syncthreads();
-        if (kt + 1 < nkt && !(p.pooled & 1024)) {                    // next tile's loads fly during the MFMAs below
-            const int64_t koff = (int64_t)(kt + 1) * TILE_ROW_BYTES;
-#pragma unroll
-            for (int m = 0; m < NA; ++m) sa[m].load(a_src + (int64_t)m * K * X::BYTES + koff, lda_bytes, rows_valid);
-            sb.load(w_src + koff, ldw_bytes, cols_valid);
-        }
-        if (!POOLED) {
-            if (!(p.pooled & 512)) tile_mma<T, 4, 4>(acc, ldsA, 64 * wr, ldsB, 64 * wc);
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                frag bf[4];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) bf[ct] = lds_frag<T>(ldsB, 64 * wc + 16 * ct + r16, 4 * ks + lg);
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
-                    float xm[M_][X::EPL];
-#pragma unroll
-                    for (int m = 0; m < M_; ++m)
-                        X::unpack(lds_frag<T>(ldsA + m * TILE, 64 * wr + 16 * rt + r16, 4 * ks + lg), xm[m]);
-                    frag pa = X::zero();
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        if (ct < nct) {
-                            if (ct == 0 || head[ct] != head[ct - 1]) {
-                                float pv[X::EPL];
-#pragma unroll
-                                for (int j = 0; j < X::EPL; ++j) {
-                                    float v = pr[rt][ct][0] * xm[0][j];
-#pragma unroll
-                                    for (int m = 1; m < M_; ++m) v = fmaf(pr[rt][ct][m], xm[m][j], v);
-                                    pv[j] = v;
-                                }
-                                pa = X::pack(pv);
-                            }
-                            acc[rt][ct] = X::mma(pa, bf[ct], acc[rt][ct]);
-                        }
-                    }
-                }
+    if (!POOLED) {
+        // LDS-DMA, two buffers, one barrier per K tile: barrier (tile kt landed, tile kt-1 consumed) -> issue kt+1 -> MFMAs of kt
+        dma_tile<128, 256>(a_src, lda_bytes, rows_valid, ldsA);
+        dma_tile<128, 256>(w_src, ldw_bytes, cols_valid, ldsB);
+        for (int kt = 0; kt < nkt; ++kt) {
+            char* curA = ldsA + (kt & 1) * 2 * TILE;
+            char* curB = ldsB + (kt & 1) * 2 * TILE;
+            __syncthreads();
+            if (kt + 1 < nkt && !(p.pooled & 1024)) {
+                const int64_t koff = (int64_t)(kt + 1) * TILE_ROW_BYTES;
+                dma_tile<128, 256>(a_src + koff, lda_bytes, rows_valid, ldsA + ((kt + 1) & 1) * 2 * TILE);
+                dma_tile<128, 256>(w_src + koff, ldw_bytes, cols_valid, ldsB + ((kt + 1) & 1) * 2 * TILE);
             }
+            if (!(p.pooled & 512)) tile_mma<T, 4, 4>(acc, curA, 64 * wr, curB, 64 * wc);
         }
     }
-
     if (p.pooled & 256) return;
     // ---------------- epilogue ----------------
     const elem* bias = reinterpret_cast<const elem*>(p.bias);
@@ -195,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 template <typename T, int M_, bool POOLED>
 static void launch_one(const GemmNtArgs& a, hipStream_t s) {
     constexpr int NA = POOLED ? M_ : 1;
-    const size_t smem = (size_t)(NA + 1) * 128 * TILE_ROW_BYTES;
+    const size_t smem = (size_t)(POOLED ? (NA + 1) : 4) * 128 * TILE_ROW_BYTES;
     dim3 grid(xcd_grid((unsigned)((a.R + 127) / 128), (unsigned)((a.N + 127) / 128))), block(256);
     auto kern = gemm_nt_kernel<T, M_, POOLED>;
     if (smem > 64 * 1024)

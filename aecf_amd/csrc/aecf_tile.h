@@ -68,6 +68,28 @@ struct DirectStage {
     }
 };
 
+// LDS-DMA staging of a ROWS x 128 B tile (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  The LDS
+// destination of one wave-instruction is linear (wave-uniform base + lane * 16), which is exactly this tile
+// format's physical chunk order (chunk c = tid + NT*i at byte 16*c); the XOR swizzle therefore goes on the per-lane
+// SOURCE address: physical chunk ph of row r holds logical chunk ph ^ s(r).  Rows past rows_valid re-read the last
+// valid row (their products are never stored).  Completion: the DMA counts on vmcnt; hipcc drains it in front
+// of the next __syncthreads(), so "barrier; issue next tile; compute this tile" overlaps one tile of loads.
+typedef __attribute__((address_space(3))) void lds_void_t;
+template <int ROWS, int NT>
+__device__ __forceinline__ void dma_tile(const char* __restrict__ src, int64_t ld_bytes, int rows_valid, char* lds) {
+    constexpr int N = ROWS * 8 / NT;
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = threadIdx.x + NT * i;
+        const int row = c >> 3, ph = c & 7;
+        const int rowc = row < rows_valid ? row : rows_valid - 1;
+        const int logical = ph ^ (((row >> 1) ^ (row >> 4)) & 7);
+        __builtin_amdgcn_global_load_lds(src + rowc * ld_bytes + logical * 16,
+                                         (lds_void_t*)(lds + (wbase + NT * i) * 16), 16, 0, 0);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ typename Tr<T>::frag lds_frag(const char* lds, int row, int chunk) {
     return *reinterpret_cast<const typename Tr<T>::frag*>(lds + lds_off(row, chunk));
