@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct BF16 {};
 struct F32 {};
@@ -25,8 +26,10 @@ __device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
     __bf16 h = (__bf16)f;            // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
     return (unsigned int)__builtin_bit_cast(unsigned short, h);
 }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    bf16x2 v = __builtin_convertvector(f32x2{lo, hi}, bf16x2);      // ONE v_cvt_pk_bf16_f32 (both halves, RNE)
+    return __builtin_bit_cast(unsigned int, v);
 }
 
 template <typename T> struct Tr;

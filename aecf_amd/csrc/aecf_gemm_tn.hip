@@ -404,12 +404,14 @@ static void launch_wj(const GemmTnArgs& a, hipStream_t s) {
 }
 
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s) {
+    // bf16: transposed-LDS-read kernel (aecf_gemm_tn_tr.hip); f32: register-transposed staging (this file)
     if (!a.pooled) {
-        if (dtype == 0) launch_wj<BF16, 1, false>(a, s); else launch_wj<F32, 1, false>(a, s);
+        if (dtype == 0) launch_gemm_tn_tr(a, s); else launch_wj<F32, 1, false>(a, s);
         return;
     }
+    if (dtype == 0) launch_gemm_tn_tr(a, s);
     AECF_DISPATCH_M(a.M, {
-        if (dtype == 0) { launch_wj<BF16, M_, true>(a, s); launch_u<BF16, M_>(a, s); }
+        if (dtype == 0) launch_u<BF16, M_>(a, s);
         else { launch_wj<F32, M_, true>(a, s); launch_u<F32, M_>(a, s); }
     });
 }

@@ -1,0 +1,321 @@
+// gemm_tn, bf16, gfx950 transposed-LDS-read form:  out[j][k] = sum_b lhs[b][j] * rhs(b,k)   (see aecf_gemm_tn.hip).
+//
+// The reduction index (the batch) is the slow axis of both row-major operands.  gfx950 can read an MFMA operand
+// TRANSPOSED out of LDS (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block of 16-bit values and
+// every lane receives one column), so the tiles stay in their natural [batch row][feature] order:
+//   * lhs tile  [64 batch rows][128 features]: global_load_lds (LDS-DMA), double buffered -- no register round
+//     trip, no vector instructions at all;
+//   * rhs tile, plain GEMM: the same;
+//   * rhs tile, POOLED: rhs(b,k) = sum_m probs[b, head(j), m] * x[b,m,k].  Each thread loads two 16-byte chunks of
+//     each modality row, forms the pooled chunk per head slot (v_pk_fma_f32, one v_cvt_pk_bf16_f32 per pair) and
+//     writes it row-major with one ds_write_b128 -- no transposition work;
+//   * lhs column sums (the bias gradients): one extra MFMA against an all-ones operand.
+// LDS image of a [64][128] tile: 8-row x 32-column subtiles of 512 B, 16-byte chunk ch of row r at
+//     2048 (r >> 3) + 512 (ch >> 2) + 64 (r & 7) + 16 ((ch & 3) ^ ((r >> 2) & 3))
+// (cdna_hip_programming.md T10, image (a)): the DMA writes, the b128 writes and the transposed reads are bank-conflict
+// free, and all 24 transposed reads of a wave's step share 4 address registers (the rest are immediates).
+// Block = 512 threads (8 waves as 4 (j) x 2 (k)), block tile 128 x 128, wave tile 32 x 64, 64 batch rows per step.
+// Output: float32 partial slabs per batch split (deterministic; reduced by reduce_segments).
+#include "aecf_kernels.h"
+#include "aecf_tile.h"
+
+namespace aecf {
+
+namespace {
+
+constexpr int TRB = 64;                        // batch rows per step
+constexpr int TR_TILE = TRB * 256;             // bytes of one [64][128 bf16] tile
+
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+
+__device__ __forceinline__ int tr_off(int row, int ch) {
+    return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
+// LDS-DMA of a [64 rows][256 B] tile.  The DMA destination is lane-linear: chunk c = tid + 512 i lands at byte 16 c,
+// which in this image is row 8 (c >> 7) + ((c >> 2) & 7), chunk 4 ((c >> 5) & 3) + ((c & 3) ^ ((row >> 2) & 3)): the
+// permutation goes on the per-lane SOURCE address (a wave-instruction still reads 8 rows x 128 contiguous bytes).
+// Rows >= rows_valid re-read the last valid row, chunks >= chunks_valid re-read chunk 0 (in bounds; the caller
+// zeroes or never stores what they produce).  src is wave-uniform; the per-lane part is a 32-bit offset.
+__device__ __forceinline__ void dma_tile_tr(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid,
+                                            int chunks_valid, char* lds) {
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = threadIdx.x + 512 * i;
+        const int row = 8 * (c >> 7) + ((c >> 2) & 7);
+        const int rowc = row < rows_valid ? row : rows_valid - 1;
+        int logical = 4 * ((c >> 5) & 3) + ((c & 3) ^ ((row >> 2) & 3));
+        logical = logical < chunks_valid ? logical : 0;
+        const unsigned int voff = (unsigned)rowc * ld_bytes + (unsigned)logical * 16u;
+        __builtin_amdgcn_global_load_lds(src + voff, (lds_void_t*)(lds + (wbase + 512 * i) * 16), 16, 0, 0);
+    }
+}
+
+// NOTE: the pooling below is written with scalar fmaf on purpose and this file is built with -fno-slp-vectorize:
+// the packed form (v_pk_mul_f32 / v_pk_fma_f32 with op_sel broadcast of the probability) gave run-to-run different
+// low halves on MI355X at full size (profiles/r01_pmc_notes.md).
+// MFMA operand (8 consecutive batch rows 32 ks + 8 lg .. + 7 of feature column col0 + r16) by two transposed reads
+__device__ __forceinline__ u32x4 tr_frag(const char* tile, int addr_lo, int addr_hi) {
+    const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(tile + addr_lo));
+    const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(tile + addr_hi));
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l[0], l[1], h[0], h[1]};
+}
+
+template <int M_, bool POOLED, int MAXS>
+__global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(GemmTnArgs p) {
+    using X = Tr<BF16>;
+    constexpr int RT = 2, CT = 4;
+    constexpr int PLN = POOLED ? (TRB * MAXS * M_ + 511) / 512 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int E = p.E, H = p.H;
+    const int EJ = p.Ej > 0 ? p.Ej : p.E;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+
+    const unsigned int nK = (unsigned)((E + 127) / 128), nJt = (unsigned)((EJ + 127) / 128);
+    unsigned int split_u, tile_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)p.splits, nK * nJt, split_u, tile_u)) return;
+    const int kt_idx = (int)(tile_u % nK), jt_idx = (int)(tile_u / nK);
+    const int j0 = jt_idx * 128, k0 = kt_idx * 128;
+    const int split = (int)split_u;
+    const int64_t rbeg = (int64_t)split * p.rows_per_split;
+    const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
+    const int jrows = (EJ - j0) >= 128 ? 128 : (EJ - j0);     // multiples of 64
+    const int kcols = (E - k0) >= 128 ? 128 : (E - k0);
+
+    const int h_first = POOLED ? j0 / p.hd : 0;
+    const int h_last = POOLED ? (j0 + jrows - 1) / p.hd : 0;
+    const int nslots = h_last - h_first + 1;
+
+    // LDS carve: lhs tile x2 | rhs tiles (POOLED: one per head slot; plain: x2) | probabilities x2
+    char* ldsL = smem;
+    char* ldsR = smem + 2 * TR_TILE;
+    float* pl = reinterpret_cast<float*>(ldsR + (POOLED ? MAXS : 2) * TR_TILE);       // [2][TRB][MAXS][M]
+
+    // wave tile 32 (j) x 64 (k)
+    const int j0w = 32 * (w >> 1), k0w = 64 * (w & 1);
+    const bool wave_on = j0w < jrows && k0w < kcols;
+    const int wslot = POOLED ? ((j0 + (j0w < jrows ? j0w : 0)) / p.hd - h_first) : 0;
+    const bool do_cs = p.colsum != nullptr && kt_idx == 0 && k0w == 0;
+
+    // transposed-read addresses: lane 4q+pp of group lg reads row 32 ks + 8 lg + 4 hh + q, columns 4 pp .. 4 pp + 3
+    // of the 16-column block blk (chunk 2 blk + (pp >> 1)):
+    //   off = 8192 ks + 2048 lg + 512 (blk >> 1) + 256 hh + 64 q + 16 ((2 (blk & 1) + (pp >> 1)) ^ (2 (lg & 1) + hh)) + 8 (pp & 1)
+    // -> 4 per-lane values tx[blk & 1][hh]; ks and blk >> 1 are immediates, the wave's block origin a uniform add.
+    const int q = r16 >> 2, pp = r16 & 3;
+    int tx[2][2];
+#pragma unroll
+    for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            tx[b1][hh] = 2048 * lg + 64 * q + 8 * (pp & 1) + 256 * hh + 16 * ((2 * b1 + (pp >> 1)) ^ (2 * (lg & 1) + hh));
+    const int a_org = 512 * (w >> 1);                     // lhs block 2 (w >> 1) + rt
+    const int b_org = 1024 * (w & 1);                     // rhs block 4 (w & 1) + ct
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 csacc[RT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) csacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* lhs = reinterpret_cast<const char*>(p.lhs);
+    const char* rhs = reinterpret_cast<const char*>(p.rhs);
+    const unsigned int ldl = (unsigned)EJ * 2u;
+    const unsigned int ldr = (unsigned)(POOLED ? M_ : 1) * (unsigned)E * 2u;
+
+    // pooling role of this thread: batch row prow, 16-byte chunks pc and pc + 8 of the 128-feature slice
+    const int prow = threadIdx.x >> 3, pc = threadIdx.x & 7;
+    const bool c_on[2] = {8 * pc < kcols, 8 * (pc + 8) < kcols};
+    u32x4 Rb[POOLED ? M_ : 1][2];
+    float plr[PLN];
+
+    auto issue_dma = [&](int64_t base, int buf) {
+        const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        dma_tile_tr(lhs + base * (int64_t)ldl + (int64_t)j0 * 2, ldl, nvalid, jrows >> 3, ldsL + buf * TR_TILE);
+        if (!POOLED) dma_tile_tr(rhs + base * (int64_t)ldr + (int64_t)k0 * 2, ldr, nvalid, kcols >> 3, ldsR + buf * TR_TILE);
+    };
+    auto load_regs = [&](int64_t base) {
+        if (POOLED) {
+            const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+            const float* pu = p.probs + (base * H + h_first) * M_;              // wave-uniform bases, 32-bit lane offsets
+            const char* xu = rhs + base * (int64_t)ldr + (int64_t)k0 * 2;
+#pragma unroll
+            for (int i = 0; i < PLN; ++i) {
+                const int idx = threadIdx.x + 512 * i;          // (t, s, m) with MAXS slots per row
+                const int t = idx / (MAXS * M_), rem = idx - t * (MAXS * M_);
+                const int sl = rem / M_, m = rem - sl * M_;
+                plr[i] = (idx < TRB * MAXS * M_ && sl < nslots && t < nvalid)
+                             ? pu[(unsigned)(t * H * M_ + sl * M_ + m)] : 0.f;
+            }
+            const unsigned int xoff = (unsigned)prow * ldr + 16u * (unsigned)pc;
+#pragma unroll
+            for (int m = 0; m < M_; ++m)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c_on[c] && prow < nvalid)
+                        Rb[m][c] = *reinterpret_cast<const u32x4*>(xu + (size_t)m * E * 2 + 128 * c + xoff);
+                    else
+                        Rb[m][c] = u32x4{0u, 0u, 0u, 0u};
+                }
+        }
+    };
+    auto store_pl = [&](int buf) {
+        if (POOLED) {
+#pragma unroll
+            for (int i = 0; i < PLN; ++i) {
+                const int idx = threadIdx.x + 512 * i;
+                if (idx < TRB * MAXS * M_) pl[buf * (TRB * MAXS * M_) + idx] = plr[i];
+            }
+        }
+    };
+
+    if (rbeg < rend) {                                    // (a trailing split can be empty: its slab is all zeros)
+        issue_dma(rbeg, 0);
+        load_regs(rbeg);
+        store_pl(0);
+    }
+    int cur = 0;
+    for (int64_t base = rbeg; base < rend; base += TRB, cur ^= 1) {
+        const bool more = base + TRB < rend;
+        const int nvalid_cur = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        __syncthreads();               // MMA of the previous step done; this step's DMA tiles and probabilities visible
+        if (POOLED) {
+            const float* plc = pl + cur * (TRB * MAXS * M_) + prow * (MAXS * M_);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x2 xv[M_][4];
+#pragma unroll
+                for (int m = 0; m < M_; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        xv[m][i] = f32x2{__uint_as_float(Rb[m][c][i] << 16), __uint_as_float(Rb[m][c][i] & 0xffff0000u)};
+                const int woff = tr_off(prow, pc + 8 * c);
+#pragma unroll
+                for (int sl = 0; sl < MAXS; ++sl) {
+                    if (sl < nslots) {
+                        f32x2 pv[4];
+                        const float p0 = plc[sl * M_];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pv[i] = f32x2{xv[0][i][0] * p0, xv[0][i][1] * p0};
+#pragma unroll
+                        for (int m = 1; m < M_; ++m) {
+                            const float pm = plc[sl * M_ + m];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pv[i] = f32x2{fmaf(xv[m][i][0], pm, pv[i][0]), fmaf(xv[m][i][1], pm, pv[i][1])};
+                        }
+                        u32x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                        *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
+                    }
+                }
+            }
+            __syncthreads();                              // pooled tiles visible
+        } else {
+            const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+            if (nvalid < TRB) {                           // ragged last step: zero the rhs rows that do not exist
+                for (int c = threadIdx.x; c < (TRB - nvalid) * 16; c += 512)
+                    *reinterpret_cast<u32x4*>(ldsR + cur * TR_TILE + tr_off(nvalid + (c >> 4), c & 15)) = u32x4{0u, 0u, 0u, 0u};
+                __syncthreads();
+            }
+        }
+        if (more) {                                       // next step's loads fly behind this step's MFMAs
+            issue_dma(base + TRB, cur ^ 1);
+            load_regs(base + TRB);
+        }
+        if (wave_on) {
+            const char* lt = ldsL + cur * TR_TILE;
+            const char* rt_tile = ldsR + (POOLED ? wslot : cur) * TR_TILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    a[rt] = tr_frag(lt + a_org + 8192 * ks, tx[rt][0], tx[rt][1]);
+                if (do_cs) {                              // row sums of lhs: product with ones over the rows that exist
+                    u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                    if (nvalid_cur < TRB) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const int kk = 32 * ks + 8 * lg + 2 * d;
+                            ones[d] = (kk < nvalid_cur ? 0x3f80u : 0u) | (kk + 1 < nvalid_cur ? 0x3f800000u : 0u);
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) csacc[rt] = X::mma(a[rt], ones, csacc[rt]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const u32x4 b = tr_frag(rt_tile + b_org + 8192 * ks + 512 * (ct >> 1), tx[ct & 1][0], tx[ct & 1][1]);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = X::mma(a[rt], b, acc[rt][ct]);
+                }
+            }
+        }
+        if (more) store_pl(cur ^ 1);
+    }
+
+    // ---- slab stores: acc[rt][ct][r] = out[j0 + j0w + 16 rt + 4 lg + r][k0 + k0w + 16 ct + r16] ----
+    float* out = p.out + (int64_t)split * EJ * E;
+    if (wave_on) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (k0w + 16 * ct < kcols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        out[(int64_t)(j0 + j0w + 16 * rt + 4 * lg + r) * E + k0 + k0w + 16 * ct + r16] = acc[rt][ct][r];
+                }
+        if (do_cs && r16 == 0) {                          // every column of the ones-product holds the row sums
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    p.colsum[(int64_t)split * EJ + j0 + j0w + 16 * rt + 4 * lg + r] = csacc[rt][r];
+        }
+    }
+}
+
+template <int M_, bool POOLED, int MAXS>
+void launch_one(const GemmTnArgs& a, hipStream_t s) {
+    size_t smem = (size_t)2 * TR_TILE + (size_t)(POOLED ? MAXS : 2) * TR_TILE;
+    if (POOLED) smem += (size_t)2 * TRB * MAXS * M_ * sizeof(float);
+    const int nJ = ((a.Ej > 0 ? a.Ej : a.E) + 127) / 128;
+    dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)(((a.E + 127) / 128) * nJ))), block(512);
+    auto kern = gemm_tn_tr_kernel<M_, POOLED, MAXS>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a);
+}
+
+}  // namespace
+
+// head slots a block needs = the most heads any aligned 128-row window of the E output rows touches
+static int max_slots_128(int E, int hd) {
+    int mx = 1;
+    for (int j0 = 0; j0 < E; j0 += 128) {
+        const int j1 = (j0 + 128 < E ? j0 + 128 : E) - 1;
+        const int n = j1 / hd - j0 / hd + 1;
+        if (n > mx) mx = n;
+    }
+    return mx;
+}
+
+// bf16 only; head_dim % 32 == 0 (a wave's 32 output rows lie inside one head)
+void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s) {
+    if (!a.pooled) { launch_one<1, false, 1>(a, s); return; }
+    const int ns = max_slots_128(a.E, a.hd);
+    AECF_DISPATCH_M(a.M, {
+        if (ns <= 2) launch_one<M_, true, 2>(a, s);
+        else launch_one<M_, true, 4>(a, s);
+    });
+}
+
+}  // namespace aecf

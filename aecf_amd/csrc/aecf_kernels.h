@@ -104,6 +104,7 @@ struct GemmTnArgs {
     int pooled;
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
+void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b64_tr_b16 form (main product only)
 
 // dst[g][i] = sum_s src[g][s*n[g] + i] for each of N segments, one launch
 struct ReduceSegs {

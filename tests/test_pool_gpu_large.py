@@ -100,6 +100,11 @@ def test_full_size_bf16(name):
     for k in ("y", "w", "mw", "ent", "rate", "dx"):
         assert torch.equal(part[k], full[k][sl]), k
 
+    # run-to-run determinism: no float atomics, fixed-order reductions -> a second run is bit-identical
+    again = _run(pool, query, x, dy, U, dt)
+    for k in ("y", "dx", "dw_in", "db_in", "dw_out", "db_out", "dq"):
+        assert torch.equal(again[k], full[k]), k
+
     # linearity of the backward in dy (exact for a power of two)
     twice = _run(pool, query, x, dy * 2, U, dt)
     assert torch.equal(twice["dx"], full["dx"] * 2)
