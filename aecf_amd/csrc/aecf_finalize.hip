@@ -10,24 +10,31 @@
 
 namespace aecf {
 
-// 8 consecutive lanes per output element: lane g sums the splits k = g, g+8, ... (coalesced across elements is not
-// needed: slabs are [split][element], so the 8 lanes read 8 different slabs at the same offset), then a fixed-order
-// butterfly adds the 8 partials -> deterministic, and short loops even for hundreds of splits.
+// One wave reduces 64 consecutive output elements: lane = (g = lane >> 4, e = lane & 15) reads the float4 at elements
+// 4e..4e+3 of the splits k = g, g+4, g+8, ... (a 16-lane group reads 256 contiguous bytes of one slab), then a
+// fixed-order butterfly over the 4 groups adds the partials -> deterministic, coalesced, short loops even for
+// hundreds of splits.  Every segment length is a multiple of 4.
 __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs r) {
-    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
-    const int g = threadIdx.x & 7;
+    const int lane = threadIdx.x & 63, g = lane >> 4, e = lane & 15;
+    int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + e;      // float4 index over all segments
 #pragma unroll
     for (int s = 0; s < ReduceSegs::N; ++s) {
-        if (i < r.n[s]) {
-            float a = 0.f;
-            for (int k = g; k < r.splits[s]; k += 8) a += r.src[s][(int64_t)k * r.n[s] + i];
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
-            a += __shfl_xor(a, 4, 64);
-            if (g == 0) r.dst[s][i] = a;
+        const int64_t nq = (r.n[s] + 63) / 64 * 16;                            // segments start on a wave boundary
+        if (q < nq) {
+            const bool on = 4 * q < r.n[s];
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (on)
+                for (int k = g; k < r.splits[s]; k += 4)
+                    a += *reinterpret_cast<const f32x4*>(r.src[s] + (int64_t)k * r.n[s] + 4 * q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a[c] += __shfl_xor(a[c], 16, 64);
+                a[c] += __shfl_xor(a[c], 32, 64);
+            }
+            if (on && g == 0) *reinterpret_cast<f32x4*>(r.dst[s] + 4 * q) = a;
             return;
         }
-        i -= r.n[s];
+        q -= nq;
     }
 }
 
@@ -85,9 +92,9 @@ __global__ __launch_bounds__(256) void fin_dquery_kernel(FinalizeArgs p) {
 }
 
 void launch_reduce_segments(const ReduceSegs& r, hipStream_t s) {
-    int64_t total = 0;
-    for (int i = 0; i < ReduceSegs::N; ++i) total += r.n[i];
-    reduce_segments_kernel<<<dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, s>>>(r);
+    int64_t waves = 0;                                   // one wave per 64 elements, segments padded to waves
+    for (int i = 0; i < ReduceSegs::N; ++i) waves += (r.n[i] + 63) / 64;
+    reduce_segments_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s>>>(r);
 }
 
 void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s) {
