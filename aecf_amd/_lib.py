@@ -13,7 +13,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaecf_hip.so")
 
-AECF_ABI_VERSION = 1
+AECF_ABI_VERSION = 2
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_FWD_STAGES = 4
@@ -48,6 +48,8 @@ class PoolFwdArgs(Structure):
         ("entropy", c_void_p), ("mask_rate", c_void_p), ("saved_probs", c_void_p),
         ("saved_o", c_void_p), ("saved_v", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
+        ("info_attn_w", c_void_p), ("info_masked_w", c_void_p), ("info_entropy", c_void_p),
+        ("info_mask_rate", c_void_p),
     ]
 
 
@@ -60,6 +62,7 @@ class PoolBwdArgs(Structure):
         ("dquery", c_void_p), ("dw_in", c_void_p), ("db_in", c_void_p), ("dw_out", c_void_p),
         ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
+        ("grad_dtype", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -80,7 +83,7 @@ _SYMBOLS = [
      [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_entropy_loss_workspace_bytes", c_size_t, [c_int64]),
     ("aecf_entropy_loss_fwd_bwd", c_int,
-     [c_int64, c_int32, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+     [c_int64, c_int32, c_int32, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_sdpa_forward", c_int,
      [c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p]),

@@ -178,7 +178,8 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     GateArgs g;
     g.x = a->x; g.a_hi = a_hi; g.a_lo = a_lo; g.kpm = a->key_padding_mask; g.uniforms = a->uniforms;
     g.probs = a->saved_probs; g.attn_w = a->attn_w; g.masked_w = a->masked_w; g.entropy = a->entropy;
-    g.mask_rate = a->mask_rate; g.B = d->batch; g.M = M; g.E = E; g.H = H;
+    g.mask_rate = a->mask_rate; g.i_attn_w = a->info_attn_w; g.i_masked_w = a->info_masked_w;
+    g.i_entropy = a->info_entropy; g.i_mask_rate = a->info_mask_rate; g.B = d->batch; g.M = M; g.E = E; g.H = H;
     g.mask = make_mask_cfg(d->mask_mode, d->min_active, d->base_mask_prob, d->entropy_target, d->eps, M);
     launch_gate_fwd(d->dtype, g, s);
     mark(ev, 2, s);
@@ -206,6 +207,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
         !a->dquery || !a->dw_in || !a->db_in || !a->dw_out || !a->db_out || !a->workspace)
         return AECF_ERR_NULL_POINTER;
     if (a->d_entropy && !a->attn_w) return AECF_ERR_NULL_POINTER;
+    if (a->grad_dtype != AECF_F32 && !(a->grad_dtype == AECF_BF16 && d->dtype == AECF_BF16)) return AECF_ERR_UNSUPPORTED;
     const BwdWs L = bwd_layout(d);
     if (a->workspace_bytes < L.total) return AECF_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -268,17 +270,21 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     ReduceSegs rs;
     for (int i = 0; i < ReduceSegs::N; ++i) rs.splits[i] = L.splits;
     rs.splits[4] = L.u_splits;
-    rs.src[0] = (const float*)(ws + L.slab_o); rs.dst[0] = a->dw_out;                    rs.n[0] = (int64_t)E * E;
-    rs.src[1] = (const float*)(ws + L.cs_o);   rs.dst[1] = a->db_out;                    rs.n[1] = E;
-    rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = a->dw_in + (size_t)2 * E * E; rs.n[2] = (int64_t)E * E;
-    rs.src[3] = (const float*)(ws + L.cs_v);   rs.dst[3] = a->db_in + 2 * E;             rs.n[3] = E;
-    rs.src[4] = (const float*)(ws + L.u_slab); rs.dst[4] = u;                            rs.n[4] = (int64_t)HPAD * E;
+    const int gb = a->grad_dtype == AECF_BF16 ? 1 : 0;
+    const size_t gsz = gb ? 2 : 4;                                    // bytes per parameter-gradient element
+    for (int i = 0; i < ReduceSegs::N; ++i) rs.dst_bf16[i] = gb;
+    rs.dst_bf16[4] = 0;                                               // u stays float32 (internal)
+    rs.src[0] = (const float*)(ws + L.slab_o); rs.dst[0] = a->dw_out;                              rs.n[0] = (int64_t)E * E;
+    rs.src[1] = (const float*)(ws + L.cs_o);   rs.dst[1] = a->db_out;                              rs.n[1] = E;
+    rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = (char*)a->dw_in + (size_t)2 * E * E * gsz; rs.n[2] = (int64_t)E * E;
+    rs.src[3] = (const float*)(ws + L.cs_v);   rs.dst[3] = (char*)a->db_in + (size_t)2 * E * gsz;  rs.n[3] = E;
+    rs.src[4] = (const float*)(ws + L.u_slab); rs.dst[4] = u;                                      rs.n[4] = (int64_t)HPAD * E;
     launch_reduce_segments(rs, s);
 
     FinalizeArgs f;
     f.w_in = a->w_in; f.query = a->query; f.qs = qs; f.u = u; f.dqp = (float*)(ws + L.dqp);
     f.dq_part = (float*)(ws + L.dq_part); f.dw_in = a->dw_in;
-    f.db_in = a->db_in; f.dquery = a->dquery; f.E = E; f.H = H; f.hd = hd; f.scale = scale;
+    f.db_in = a->db_in; f.dquery = a->dquery; f.E = E; f.H = H; f.hd = hd; f.scale = scale; f.grad_bf16 = gb;
     launch_finalize(d->dtype, f, s);
     mark(ev, 7, s);
     return launch_status();
@@ -311,13 +317,14 @@ int aecf_curriculum_mask_backward(int64_t rows, int32_t L, int32_t mode, float e
 
 size_t aecf_entropy_loss_workspace_bytes(int64_t n) { (void)n; return 1024 * sizeof(float); }
 
-int aecf_entropy_loss_fwd_bwd(int64_t n, int32_t last_seq_len, float entropy_target, const float* entropy,
-                              float upstream, float* loss, float* d_entropy, void* workspace, void* stream) {
+int aecf_entropy_loss_fwd_bwd(int64_t n, int32_t dtype, int32_t last_seq_len, float entropy_target, const void* entropy,
+                              float upstream, void* loss, float* d_entropy, void* workspace, void* stream) {
     if (n <= 0) return AECF_ERR_BAD_DIMS;
+    if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
     if (!entropy || !loss || !workspace) return AECF_ERR_NULL_POINTER;
     const double max_ent = last_seq_len > 1 ? log((double)last_seq_len) : 0.0;   // ref :307
     const float target = (float)(max_ent * (double)entropy_target);
-    launch_entropy_loss(n, target, entropy, upstream, loss, d_entropy, (float*)workspace, (hipStream_t)stream);
+    launch_entropy_loss(dtype, n, target, entropy, upstream, loss, d_entropy, (float*)workspace, (hipStream_t)stream);
     return launch_status();
 }
 

@@ -106,6 +106,12 @@ template <> struct Tr<F32> {
     static __device__ __forceinline__ elem from_f32(float f) { return f; }
 };
 
+// parameter-gradient element store: float32, or bf16 (one rounding of the float32 value)
+__device__ __forceinline__ void store_grad(void* base, int64_t i, float v, int bf16) {
+    if (bf16) reinterpret_cast<unsigned short*>(base)[i] = (unsigned short)f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(base)[i] = v;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -31,7 +31,16 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs r) {
                 a[c] += __shfl_xor(a[c], 16, 64);
                 a[c] += __shfl_xor(a[c], 32, 64);
             }
-            if (on && g == 0) *reinterpret_cast<f32x4*>(r.dst[s] + 4 * q) = a;
+            if (on && g == 0) {
+                if (r.dst_bf16[s]) {
+                    u32x2 o;
+                    o[0] = pack_bf16x2(a[0], a[1]);
+                    o[1] = pack_bf16x2(a[2], a[3]);
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(r.dst[s]) + 4 * q) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(r.dst[s]) + 4 * q) = a;
+                }
+            }
             return;
         }
         q -= nq;
@@ -67,12 +76,12 @@ __global__ __launch_bounds__(256) void fin_outer_kernel(FinalizeArgs p) {
     for (int jj = jg; jj < 64; jj += 4) {
         const int j = jb * 64 + jj;
         const float dq = p.dqp[j];
-        p.dw_in[(int64_t)j * E + k] = dq * qk;                                       // dW_q
-        p.dw_in[(int64_t)(E + j) * E + k] = p.qs[j] * p.u[(int64_t)(j / p.hd) * E + k];   // dW_k
+        store_grad(p.dw_in, (int64_t)j * E + k, dq * qk, p.grad_bf16);                                         // dW_q
+        store_grad(p.dw_in, (int64_t)(E + j) * E + k, p.qs[j] * p.u[(int64_t)(j / p.hd) * E + k], p.grad_bf16);   // dW_k
         part = fmaf(dq, X::to_f32(wq[(int64_t)j * E + k]), part);
         if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
-            p.db_in[j] = dq;        // db_q
-            p.db_in[E + j] = 0.f;   // db_k
+            store_grad(p.db_in, j, dq, p.grad_bf16);         // db_q
+            store_grad(p.db_in, E + j, 0.f, p.grad_bf16);    // db_k
         }
     }
     red[jg][threadIdx.x & 63] = part;
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void fin_dquery_kernel(FinalizeArgs p) {
     if (k >= p.E) return;
     float a = 0.f;
     for (int jb = 0; jb < p.E / 64; ++jb) a += p.dq_part[(int64_t)jb * p.E + k];
-    p.dquery[k] = a;
+    store_grad(p.dquery, k, a, p.grad_bf16);
 }
 
 void launch_reduce_segments(const ReduceSegs& r, hipStream_t s) {

@@ -31,6 +31,10 @@ struct GateArgs {
     float* masked_w;          // [B,M] or null
     float* entropy;           // [B] or null
     float* mask_rate;         // [B] or null
+    void* i_attn_w;           // the same four in the activation dtype (info copies), each may be null
+    void* i_masked_w;
+    void* i_entropy;
+    void* i_mask_rate;
     int64_t B;
     int M, E, H;
     MaskCfg mask;
@@ -110,9 +114,10 @@ void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b
 struct ReduceSegs {
     static constexpr int N = 5;
     const float* src[N];
-    float* dst[N];
+    void* dst[N];
     int64_t n[N];
     int splits[N];
+    int dst_bf16[N];      // 1: dst is bf16 (one rounding of the float32 sum)
 };
 void launch_reduce_segments(const ReduceSegs& r, hipStream_t s);
 
@@ -125,11 +130,12 @@ struct FinalizeArgs {
     const float* u;       // [HPAD,E] reduced
     float* dqp;           // [E] scratch
     float* dq_part;       // [E/64, E] scratch (dquery partials per j-block)
-    float* dw_in;         // [3E,E]
-    float* db_in;         // [3E]
-    float* dquery;        // [E]
+    void* dw_in;          // [3E,E]  float32, or bf16 when grad_bf16
+    void* db_in;          // [3E]
+    void* dquery;         // [E]
     int E, H, hd;
     float scale;
+    int grad_bf16;
 };
 void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s);
 
@@ -138,8 +144,8 @@ void launch_mask_fwd(int64_t rows, int L, const MaskCfg& cfg, const float* w, co
                      float* entropy, float* mask_rate, uint8_t* bits, hipStream_t s);
 void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, const float* w, const uint8_t* bits,
                      const float* d_masked, const float* d_entropy, float* d_w, hipStream_t s);
-void launch_entropy_loss(int64_t n, float target, const float* entropy, float upstream, float* loss, float* d_entropy,
-                         float* partial, hipStream_t s);
+void launch_entropy_loss(int dtype, int64_t n, float target, const void* entropy, float upstream, void* loss,
+                         float* d_entropy, float* partial, hipStream_t s);
 void launch_sdpa_fwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,
                      void* out, float* probs, hipStream_t s);
 void launch_sdpa_bwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,

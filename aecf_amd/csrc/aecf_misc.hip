@@ -111,13 +111,15 @@ __device__ __forceinline__ float nan_to_num_ref(float e) {   // nan=0, +inf=1, -
     return e;
 }
 
-__global__ __launch_bounds__(256) void entropy_loss_partial_kernel(int64_t n, float target, const float* __restrict__ e,
+template <typename T>
+__global__ __launch_bounds__(256) void entropy_loss_partial_kernel(int64_t n, float target,
+                                                                   const typename Tr<T>::elem* __restrict__ e,
                                                                    float scale_grad, float* __restrict__ d_e,
                                                                    float* __restrict__ partial) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float raw = e[i];
+        const float raw = Tr<T>::to_f32(e[i]);
         const float d = nan_to_num_ref(raw) - target;
         acc += d * d;
         if (d_e) d_e[i] = isfinite(raw) ? scale_grad * d : 0.f;
@@ -128,15 +130,16 @@ __global__ __launch_bounds__(256) void entropy_loss_partial_kernel(int64_t n, fl
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void entropy_loss_final_kernel(int nblk, float inv_n, const float* __restrict__ partial,
-                                                                 float* __restrict__ loss) {
+                                                                 typename Tr<T>::elem* __restrict__ loss) {
     __shared__ float red[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
     acc = reduce_wave(acc);
     if (lane_id() == 0) red[wave_id()] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = fmaxf((red[0] + red[1] + red[2] + red[3]) * inv_n, 0.f);
+    if (threadIdx.x == 0) loss[0] = Tr<T>::from_f32(fmaxf((red[0] + red[1] + red[2] + red[3]) * inv_n, 0.f));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -244,15 +247,21 @@ void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, cons
     else mask_bwd_kernel<32><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
 }
 
-void launch_entropy_loss(int64_t n, float target, const float* entropy, float upstream, float* loss, float* d_entropy,
-                         float* partial, hipStream_t s) {
+void launch_entropy_loss(int dtype, int64_t n, float target, const void* entropy, float upstream, void* loss,
+                         float* d_entropy, float* partial, hipStream_t s) {
     int nblk = (int)((n + 255) / 256);
     if (nblk > 1024) nblk = 1024;
     if (nblk < 1) nblk = 1;
     const float inv_n = 1.0f / (float)n;
-    entropy_loss_partial_kernel<<<dim3(nblk), dim3(256), 0, s>>>(n, target, entropy, 2.0f * inv_n * upstream, d_entropy,
-                                                                partial);
-    entropy_loss_final_kernel<<<dim3(1), dim3(256), 0, s>>>(nblk, inv_n, partial, loss);
+    if (dtype == 0) {
+        entropy_loss_partial_kernel<BF16><<<dim3(nblk), dim3(256), 0, s>>>(n, target, (const unsigned short*)entropy,
+                                                                          2.0f * inv_n * upstream, d_entropy, partial);
+        entropy_loss_final_kernel<BF16><<<dim3(1), dim3(256), 0, s>>>(nblk, inv_n, partial, (unsigned short*)loss);
+    } else {
+        entropy_loss_partial_kernel<F32><<<dim3(nblk), dim3(256), 0, s>>>(n, target, (const float*)entropy,
+                                                                         2.0f * inv_n * upstream, d_entropy, partial);
+        entropy_loss_final_kernel<F32><<<dim3(1), dim3(256), 0, s>>>(nblk, inv_n, partial, (float*)loss);
+    }
 }
 
 void launch_sdpa_fwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,

@@ -144,6 +144,11 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(GateArgs p) {
         if (bs < p.B) {
 #pragma unroll
             for (int m = 0; m < M_; ++m) p.attn_w[bs * M_ + m] = wsel[m];
+            typedef typename X::elem elem;                 // info copies in the activation dtype
+            if (p.i_attn_w) {
+#pragma unroll
+                for (int m = 0; m < M_; ++m) reinterpret_cast<elem*>(p.i_attn_w)[bs * M_ + m] = X::from_f32(wsel[m]);
+            }
             if (p.mask.mode != 0) {
                 float w[M_], u[M_], mk[M_];
 #pragma unroll
@@ -160,6 +165,12 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(GateArgs p) {
                 }
                 if (p.entropy) p.entropy[bs] = ent;
                 if (p.mask_rate) p.mask_rate[bs] = rate;
+                if (p.i_masked_w) {
+#pragma unroll
+                    for (int m = 0; m < M_; ++m) reinterpret_cast<elem*>(p.i_masked_w)[bs * M_ + m] = X::from_f32(mk[m]);
+                }
+                if (p.i_entropy) reinterpret_cast<elem*>(p.i_entropy)[bs] = X::from_f32(ent);
+                if (p.i_mask_rate) reinterpret_cast<elem*>(p.i_mask_rate)[bs] = X::from_f32(rate);
             }
         }
     }

@@ -56,12 +56,13 @@ def _require_device(t: torch.Tensor, what: str) -> None:
 # autograd bridges (one per C-ABI operator)
 # ----------------------------------------------------------------------------------------------
 class _PoolFunction(torch.autograd.Function):
-    """aecf_pool_forward / aecf_pool_backward.  Outputs: y [B,E], attn_w [B,M] f32, masked_w [B,M],
-    entropy [B], mask_rate [B] (all f32)."""
+    """aecf_pool_forward / aecf_pool_backward.  Outputs: y [B,E], attn_w [B,M], masked_w [B,M], entropy [B],
+    mask_rate [B], all in the activation dtype (the library writes the info tensors in that dtype itself; the
+    float32 attn_w it also writes is kept for the backward)."""
 
     @staticmethod
     def forward(ctx, x, q, w_in, b_in, w_out, b_out, kpm, uniforms, num_heads, mask_mode, min_active,
-                base_mask_prob, entropy_target, eps):
+                base_mask_prob, entropy_target, eps, f32_info=False):
         lib = _lib.load()
         B, M, E = x.shape
         dt = x.dtype
@@ -88,13 +89,22 @@ class _PoolFunction(torch.autograd.Function):
             mask_rate = torch.empty(B, dtype=torch.float32, device=dev)
         else:
             masked_w = entropy = mask_rate = None
+        if dt != torch.float32 and not f32_info:   # info copies in the activation dtype, written by the gate kernel
+            i_attn_w = torch.empty(B, M, dtype=dt, device=dev)
+            i_masked_w = None if masked_w is None else torch.empty(B, M, dtype=dt, device=dev)
+            i_entropy = None if entropy is None else torch.empty(B, dtype=dt, device=dev)
+            # training-mode mask_rate stays float32 (ref :275); eval mode returns it in the input dtype (ref :150-156)
+            i_mask_rate = None if (mask_rate is None or mask_mode == 1) else torch.empty(B, dtype=dt, device=dev)
+        else:
+            i_attn_w = i_masked_w = i_entropy = i_mask_rate = None
         ws_bytes = lib.aecf_pool_fwd_workspace_bytes(ctypes.byref(desc))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolFwdArgs(
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(b_out_c), _ptr(kpm),
             _ptr(uniforms), _ptr(y), _ptr(attn_w), _ptr(masked_w), _ptr(entropy), _ptr(mask_rate),
             _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(ws), ws_bytes,
-            None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd))
+            None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd),
+            _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate))
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
         ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v)
         ctx.desc = desc
@@ -102,10 +112,13 @@ class _PoolFunction(torch.autograd.Function):
         ctx.param_dtypes = (q.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
                             None if b_out is None else b_out.dtype)
         ctx.has_bias = (b_in is not None, b_out is not None)
-        outs = (y, attn_w, masked_w, entropy, mask_rate)
-        nondiff = [t for t in (masked_w, mask_rate) if t is not None]
-        if entropy is not None and mask_mode == 1:
-            nondiff.append(entropy)            # train mode: entropy is detached (ref :278)
+        if i_attn_w is not None:
+            outs = (y, i_attn_w, i_masked_w, i_entropy, mask_rate if mask_mode == 1 else i_mask_rate)
+        else:
+            outs = (y, attn_w, masked_w, entropy, mask_rate)
+        nondiff = [t for t in (outs[2], outs[4]) if t is not None]
+        if outs[3] is not None and mask_mode == 1:
+            nondiff.append(outs[3])            # train mode: entropy is detached (ref :278)
         ctx.mark_non_differentiable(*nondiff)
         return outs
 
@@ -123,20 +136,24 @@ class _PoolFunction(torch.autograd.Function):
         if d_entropy is not None and desc.mask_mode == 2:
             dent = d_entropy.to(torch.float32).contiguous()
         dx = torch.empty_like(xc)
-        dquery = torch.empty(E, dtype=torch.float32, device=dev)
-        dw_in = torch.empty(3 * E, E, dtype=torch.float32, device=dev)
-        db_in = torch.empty(3 * E, dtype=torch.float32, device=dev)
-        dw_out = torch.empty(E, E, dtype=torch.float32, device=dev)
-        db_out = torch.empty(E, dtype=torch.float32, device=dev)
+        # parameter gradients: in the parameters' own dtype when that is the activation dtype (the library rounds
+        # its float32 batch sums once), float32 otherwise (e.g. float32 master weights under bf16 activations)
+        qd, wid, bid, wod, bod = ctx.param_dtypes
+        gdt = dt if all(p is None or p == dt for p in ctx.param_dtypes) else torch.float32
+        dquery = torch.empty(E, dtype=gdt, device=dev)
+        dw_in = torch.empty(3 * E, E, dtype=gdt, device=dev)
+        db_in = torch.empty(3 * E, dtype=gdt, device=dev)
+        dw_out = torch.empty(E, E, dtype=gdt, device=dev)
+        db_out = torch.empty(E, dtype=gdt, device=dev)
         ws_bytes = lib.aecf_pool_bwd_workspace_bytes(ctypes.byref(desc))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolBwdArgs(
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(dy_c), _ptr(daw), _ptr(dent),
             _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
             _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes,
-            None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd))
+            None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd),
+            _DTYPES[gdt], 0)
         _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")
-        qd, wid, bid, wod, bod = ctx.param_dtypes
         needs = ctx.needs_input_grad
         return (dx if needs[0] else None,
                 dquery.to(qd).reshape(ctx.q_shape) if needs[1] else None,
@@ -144,7 +161,7 @@ class _PoolFunction(torch.autograd.Function):
                 db_in.to(bid) if (ctx.has_bias[0] and needs[3]) else None,
                 dw_out.to(wod) if needs[4] else None,
                 db_out.to(bod) if (ctx.has_bias[1] and needs[5]) else None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 class _MaskFunction(torch.autograd.Function):
@@ -191,14 +208,18 @@ class _EntropyLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, entropy, last_seq_len, entropy_target):
         lib = _lib.load()
-        e32 = entropy.detach().to(torch.float32).contiguous()
-        n = e32.numel()
+        ec = entropy.detach()
+        if ec.dtype not in _DTYPES:
+            ec = ec.to(torch.float32)
+        ec = ec.contiguous()
+        n = ec.numel()
         dev = entropy.device
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        dent = torch.empty_like(e32)
+        loss = torch.empty(1, dtype=ec.dtype, device=dev)
+        dent = torch.empty(ec.shape, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.aecf_entropy_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        _lib.check(lib.aecf_entropy_loss_fwd_bwd(n, last_seq_len, entropy_target, _ptr(e32), 1.0, _ptr(loss),
-                                                 _ptr(dent), _ptr(ws), _stream()), "aecf_entropy_loss_fwd_bwd")
+        _lib.check(lib.aecf_entropy_loss_fwd_bwd(n, _DTYPES[ec.dtype], last_seq_len, entropy_target, _ptr(ec), 1.0,
+                                                 _ptr(loss), _ptr(dent), _ptr(ws), _stream()),
+                   "aecf_entropy_loss_fwd_bwd")
         ctx.save_for_backward(dent)
         ctx.edtype = entropy.dtype
         return loss.reshape(()).to(entropy.dtype)

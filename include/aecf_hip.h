@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AECF_ABI_VERSION 1
+#define AECF_ABI_VERSION 2
 
 typedef enum aecf_status {
     AECF_OK = 0,
@@ -87,6 +87,12 @@ typedef struct aecf_pool_fwd_args {
     /* optional profiling hook: AECF_FWD_STAGES+1 hipEvent_t handles (caller-created); event[0] is recorded
      * before the first kernel and event[i] after stage i (see aecf_pool_stage_name). NULL = off. */
     void** stage_events;
+    /* optional copies of the four info tensors in the ACTIVATION dtype, written by the same kernel (the reference
+     * returns info in the input dtype, ref :520-543, so a bf16 caller needs no cast kernels); NULL = not wanted */
+    void* info_attn_w;           /* [B,M] dtype */
+    void* info_masked_w;         /* [B,M] dtype */
+    void* info_entropy;          /* [B]   dtype */
+    void* info_mask_rate;        /* [B]   dtype */
 } aecf_pool_fwd_args;
 
 /* Backward (autograd transpose of the above). */
@@ -104,14 +110,18 @@ typedef struct aecf_pool_bwd_args {
     const void* saved_o;         /* [B,E]                                                */
     const void* saved_v;         /* [B,M,E] or NULL (NULL: the score gradient recomputes W_v^T do per head)  */
     void* dx;                    /* [B,M,E] dtype                                        */
-    float* dquery;               /* [E]                                                  */
-    float* dw_in;                /* [3E,E]                                               */
-    float* db_in;                /* [3E]                                                 */
-    float* dw_out;               /* [E,E]                                                */
-    float* db_out;               /* [E]                                                  */
+    void* dquery;                /* [E]     grad_dtype                                   */
+    void* dw_in;                 /* [3E,E]  grad_dtype                                   */
+    void* db_in;                 /* [3E]    grad_dtype                                   */
+    void* dw_out;                /* [E,E]   grad_dtype                                   */
+    void* db_out;                /* [E]     grad_dtype                                   */
     void* workspace;
     size_t workspace_bytes;
     void** stage_events;         /* AECF_BWD_STAGES+1 hipEvent_t handles or NULL (profiling hook) */
+    /* element type of the five parameter gradients: AECF_F32, or AECF_BF16 when desc.dtype is AECF_BF16 (the
+     * float32 batch sums are rounded once, in the reduction kernel -- what autograd's cast to a bf16 parameter does) */
+    int32_t grad_dtype;
+    int32_t reserved;
 } aecf_pool_bwd_args;
 
 #define AECF_FWD_STAGES 4   /* prep, gate, vproj, outproj */
@@ -151,8 +161,10 @@ int aecf_curriculum_mask_backward(int64_t rows, int32_t L, int32_t mode, float e
  * loss[0] = mean((nan_to_num(H) - log(last_seq_len)*entropy_target)^2); d_entropy = dloss/dH * upstream.
  * partial: scratch of aecf_entropy_loss_workspace_bytes(n). */
 size_t aecf_entropy_loss_workspace_bytes(int64_t n);
-int aecf_entropy_loss_fwd_bwd(int64_t n, int32_t last_seq_len, float entropy_target,
-                              const float* entropy, float upstream, float* loss,
+/* entropy [n] and loss [1] have element type dtype (the reference computes the loss in the dtype of
+ * info['entropy']); the arithmetic and d_entropy [n] are float32. */
+int aecf_entropy_loss_fwd_bwd(int64_t n, int32_t dtype, int32_t last_seq_len, float entropy_target,
+                              const void* entropy, float upstream, void* loss,
                               float* d_entropy, void* workspace, void* stream);
 
 /* Projection-free single-head attention softmax(Q K^T * scale) V (ref aecf/AECFLayer.py:556-581).
