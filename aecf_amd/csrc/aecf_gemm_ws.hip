@@ -1,0 +1,231 @@
+// Weight-stationary streaming GEMM for the fusion pool's projections, bf16, gfx950:
+//     C[r][n] = sum_k A[r][k] W[n][k] + bias[n]          R = B or B*M rows (huge), N, K <= 512 (tiny)
+// A normal tiled GEMM re-stages the SAME small weight matrix for every row tile and spends its time in
+// prologues, barriers and epilogues of 8-step K loops.  Here the weights never move:
+//   * a block owns 256 output columns; each of its 8 waves keeps its 32 x K slice of W in REGISTERS as MFMA operands
+//     (K = 512: 128 VGPRs) for the whole kernel -- loaded once;
+//   * the block walks down its share of the rows; each step a [rows x K] tile of A is copied global -> LDS by the DMA
+//     engine (global_load_lds, two buffers: the copy of step s+1 flies behind the MFMAs of step s), and every wave
+//     multiplies the whole tile against its resident weights: 2 LDS operand reads feed 4 MFMAs;
+//   * the product is formed transposed (weights as the MFMA A operand), so a lane ends up with 8 consecutive output
+//     columns of ONE row: a 16-byte store, and -- for the value projection -- all M modality products of a sample in
+//     the same lane, which makes the softmax-weighted sum o = sum_m p_m V_m a per-lane FMA.
+// Modes:  PLAIN  C = A W^T + bias                                  (out-projection, dout = dy W_o)
+//         VPROJ  rows (b,m) of x:  V[b,m,:] = x[b,m,:] W_v^T + b_v (saved for the backward, optional) and
+//                o[b,n] = sum_m probs[b, head(n), m] V[b,m,n]
+// One barrier per step; LDS tile rows are K*2 bytes with the 16-byte chunk index XOR-ed with the MFMA column index
+// (bank-conflict-free ds_read_b128; the DMA destination is lane-linear, so the XOR is applied to the source address).
+#include "aecf_kernels.h"
+#include "aecf_tile.h"
+
+namespace aecf {
+
+namespace {
+
+enum { WS_PLAIN = 0, WS_VPROJ = 1 };
+
+// copy NROWS rows (K bf16 each) to an LDS tile; row r's physical chunk p holds logical chunk p ^ key(r),
+// key(r) = (r / KEYDIV) & 15.  Rows >= rows_valid re-read the last valid row (their outputs are never stored).
+template <int KT, int NROWS, int KEYDIV>
+__device__ __forceinline__ void ws_dma_rows(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid, char* lds) {
+    constexpr int CPR = 4 * KT;                       // 16-byte chunks per row
+    constexpr int TOTAL = NROWS * CPR;
+    constexpr int NI = (TOTAL + 511) / 512;
+    static_assert(TOTAL % 64 == 0, "whole wave-instructions");
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (wbase + 512 * i < TOTAL) {                // wave-uniform
+            const int c = threadIdx.x + 512 * i;
+            const int row = c / CPR, p = c - row * CPR;
+            const int rowc = row < rows_valid ? row : rows_valid - 1;
+            const int key = (row / KEYDIV) & 15;
+            const unsigned int voff = (unsigned)rowc * ld_bytes + (unsigned)((p ^ key) << 4);
+            __builtin_amdgcn_global_load_lds(src + voff, (lds_void_t*)(lds + (wbase + 512 * i) * 16), 16, 0, 0);
+        }
+    }
+}
+
+template <int KT, int MODE, int M_>
+__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_per_block) {
+    using X = Tr<BF16>;
+    constexpr int K = 32 * KT, ROWB = 2 * K;
+    constexpr int RT = MODE == WS_PLAIN ? 2 : M_;                 // 16-row MFMA tiles per step
+    constexpr int SROWS = 16 * RT;                                // A rows per step
+    constexpr int OROWS = MODE == WS_PLAIN ? 32 : 16;             // output rows (PLAIN) / samples (VPROJ) per step
+    constexpr int TILE = SROWS * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    const int N = p.N, H = p.H;
+    const int ncol0 = blockIdx.x * 256 + 32 * w;                  // this wave's 32 output columns
+    // output rows (PLAIN) / samples (VPROJ) of this block
+    const int64_t o_beg = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t o_all = MODE == WS_PLAIN ? p.R : p.R;           // VPROJ: R counts samples
+    const int64_t o_end = (o_beg + rows_per_block) < o_all ? (o_beg + rows_per_block) : o_all;
+    if (o_beg >= o_end) return;
+
+    // ---- resident weights: MFMA A operand, row i = 4 lg' + r of tile c  <->  column ncol0 + 8 (i >> 2) + 4 c + (i & 3)
+    //      (so that accumulator lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + 0..3 of row/sample r16)
+    const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w);
+    u32x4 wreg[KT][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3);
+        const unsigned short* wr = wsrc + (int64_t)n * K + 8 * lg;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
+    }
+    float bias[8];
+    {
+        const unsigned short* bs = reinterpret_cast<const unsigned short*>(p.bias);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bias[j] = bs ? X::to_f32(bs[ncol0 + 8 * lg + j]) : 0.f;
+    }
+    const int head = ncol0 / p.hd;                                // VPROJ: the wave's 32 columns lie in one head
+
+    // ---- LDS operand addresses: row (tile t: 16 t + r16 | modality m: r16 M + m), chunk (4 ks + lg) ^ r16
+    int xaddr[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        xaddr[v] = (MODE == WS_PLAIN ? r16 : r16 * M_) * ROWB + ((((4 * v) + lg) ^ r16) << 4);
+
+    const char* asrc = reinterpret_cast<const char*>(p.a);
+    // A rows: PLAIN row r of a [R, lda] matrix; VPROJ row (b, m) of x viewed as [B*M, K] (lda = M*K)
+    const unsigned int row_pitch = (MODE == WS_PLAIN ? (unsigned)p.lda : (unsigned)K) * 2u;
+    const int a_rows_per_o = MODE == WS_PLAIN ? 1 : M_;
+
+    auto issue = [&](int64_t o0, int buf) {                        // DMA of the step that starts at output row o0
+        const int ov = (int)((o_end - o0) < OROWS ? (o_end - o0) : OROWS);
+        ws_dma_rows<KT, SROWS, (MODE == WS_PLAIN ? 1 : M_)>(asrc + o0 * a_rows_per_o * (int64_t)row_pitch, row_pitch,
+                                                            ov * a_rows_per_o, smem + buf * TILE);
+    };
+
+    // Synchronisation: the DMA of step s+1 is issued right after the barrier of step s and retired by the
+    // s_waitcnt vmcnt(0) that FOLLOWS the MFMAs of step s (a whole step of compute later: it also retires the
+    // previous step's stores, so the count is exact); this step's stores are issued after that wait and fly
+    // behind the next step.  Reads of a buffer happen one barrier after the wait that retired its DMA.
+    issue(o_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int cur = 0;
+    for (int64_t o0 = o_beg; o0 < o_end; o0 += OROWS, cur ^= 1) {
+        __builtin_amdgcn_s_barrier();                              // tile visible to all waves; other buffer free
+        if (o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);
+        float pm[MODE == WS_VPROJ ? M_ : 1];
+        if (MODE == WS_VPROJ) {                                   // this lane's sample: weights of the wave's head
+            const int64_t b = o0 + r16;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) pm[m] = b < o_end ? p.probs[(b * H + head) * M_ + m] : 0.f;
+        }
+
+        f32x4 acc[RT][2];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* tb = smem + cur * TILE;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const int toff = (MODE == WS_PLAIN ? 16 * t * ROWB : t * ROWB) + (ks >> 2) * 256;
+                const u32x4 xf = *reinterpret_cast<const u32x4*>(tb + xaddr[ks & 3] + toff);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[t][c] = X::mma(wreg[ks][c], xf, acc[t][c]);
+            }
+        }
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tile landed (see above)
+        // ---- epilogue: lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + r (c = 0,1; r = 0..3) of row / sample r16
+        if (MODE == WS_PLAIN) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const int64_t row = o0 + 16 * t + r16;
+                u32x4 o;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    o[2 * c] = pack_bf16x2(acc[t][c][0] + bias[4 * c], acc[t][c][1] + bias[4 * c + 1]);
+                    o[2 * c + 1] = pack_bf16x2(acc[t][c][2] + bias[4 * c + 2], acc[t][c][3] + bias[4 * c + 3]);
+                }
+                if (row < o_end)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + 8 * lg) = o;
+            }
+        } else {
+            const int64_t b = o0 + r16;
+            float ov[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = 0.f;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[4 * c + r] = acc[m][c][r] + bias[4 * c + r];
+                        ov[4 * c + r] = fmaf(pm[m], v[4 * c + r], ov[4 * c + r]);
+                    }
+                if (p.v_out && b < o_end)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.v_out) + (b * M_ + m) * N + ncol0 + 8 * lg) =
+                        X::pack(v);
+            }
+            if (b < o_end)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + 8 * lg) = X::pack(ov);
+        }
+    }
+}
+
+template <int KT, int MODE, int M_>
+void launch_ws(const GemmNtArgs& a, hipStream_t s) {
+    constexpr int K = 32 * KT;
+    constexpr int RT = MODE == WS_PLAIN ? 2 : M_;
+    constexpr int OROWS = MODE == WS_PLAIN ? 32 : 16;
+    size_t smem = (size_t)2 * 16 * RT * 2 * K;
+    const int groups = a.N / 256;
+    // about one block per CU (256): chunks of whole steps
+    int64_t chunks = 256 / groups;
+    if (chunks < 1) chunks = 1;
+    int64_t rpb = (a.R + chunks - 1) / chunks;
+    rpb = (rpb + OROWS - 1) / OROWS * OROWS;
+    const int64_t nchunk = (a.R + rpb - 1) / rpb;
+    dim3 grid((unsigned)groups, (unsigned)nchunk), block(512);
+    auto kern = gemm_ws_kernel<KT, MODE, M_>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a, (int)rpb);
+}
+
+template <int MODE, int M_>
+void launch_kt(const GemmNtArgs& a, hipStream_t s) {
+    switch (a.K / 32) {
+        case 4: launch_ws<4, MODE, M_>(a, s); break;
+        case 8: launch_ws<8, MODE, M_>(a, s); break;
+        case 12: launch_ws<12, MODE, M_>(a, s); break;
+        default: launch_ws<16, MODE, M_>(a, s); break;
+    }
+}
+
+}  // namespace
+
+// shapes the weight-stationary kernel takes (bf16 only); everything else stays on the tiled kernels
+bool gemm_ws_supported(const GemmNtArgs& a) {
+    if (a.out_f32) return false;
+    if (a.K % 128 != 0 || a.K < 128 || a.K > 512 || a.N % 256 != 0) return false;
+    if (a.pooled & 1) return a.M >= 1 && a.M <= 4 && a.hd % 32 == 0 && a.lda == (int64_t)a.M * a.K;
+    return a.lda == a.K && (a.pooled >> 8) == 0;
+}
+
+void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s) {
+    if (a.pooled & 1) {
+        switch (a.M) {
+            case 1: launch_kt<WS_VPROJ, 1>(a, s); break;
+            case 2: launch_kt<WS_VPROJ, 2>(a, s); break;
+            case 3: launch_kt<WS_VPROJ, 3>(a, s); break;
+            default: launch_kt<WS_VPROJ, 4>(a, s); break;
+        }
+    } else {
+        launch_kt<WS_PLAIN, 1>(a, s);
+    }
+}
+
+}  // namespace aecf

@@ -60,6 +60,8 @@ struct GemmNtArgs {
 };
 void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
 void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s);   // pooled == 1 path
+bool gemm_ws_supported(const GemmNtArgs& a);                          // weight-stationary streaming form (bf16)
+void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s);
 
 // ---------------- backward ----------------
 // g_h[b] = W_v,h^T do_h[b] kernels (aecf_bwd_g.hip):
