@@ -47,7 +47,7 @@ __device__ __forceinline__ void ws_dma_rows(const char* __restrict__ src, unsign
 }
 
 template <int KT, int MODE, int M_>
-__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_per_block) {
+__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
     constexpr int K = 32 * KT, ROWB = 2 * K;
     constexpr int RT = MODE == WS_PLAIN ? 2 : M_;                 // 16-row MFMA tiles per step
@@ -58,9 +58,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     const int N = p.N, H = p.H;
-    const int ncol0 = blockIdx.x * 256 + 32 * w;                  // this wave's 32 output columns
+    // 1-D grid, XCD-aware: the column groups of one row chunk get ids b, b+8, ... -> same XCD, dispatched together,
+    // so the chunk's rows come from HBM once and the other groups read them from that XCD's L2 (aecf_tile.h)
+    unsigned int chunk_u, group_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(p.N / 256), chunk_u, group_u)) return;
+    const int ncol0 = (int)group_u * 256 + 32 * w;                // this wave's 32 output columns
     // output rows (PLAIN) / samples (VPROJ) of this block
-    const int64_t o_beg = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t o_beg = (int64_t)chunk_u * rows_per_block;
     const int64_t o_all = MODE == WS_PLAIN ? p.R : p.R;           // VPROJ: R counts samples
     const int64_t o_end = (o_beg + rows_per_block) < o_all ? (o_beg + rows_per_block) : o_all;
     if (o_beg >= o_end) return;
@@ -105,38 +109,91 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     // s_waitcnt vmcnt(0) that FOLLOWS the MFMAs of step s (a whole step of compute later: it also retires the
     // previous step's stores, so the count is exact); this step's stores are issued after that wait and fly
     // behind the next step.  Reads of a buffer happen one barrier after the wait that retired its DMA.
+    // VPROJ: this lane's sample, softmax weights of the wave's head, loaded ONE STEP AHEAD by inline asm (an ordinary
+    // load beside an in-flight LDS-DMA makes hipcc wait vmcnt(0) in front of the first MFMA, which would serialise
+    // the DMA with the compute); the end-of-step s_waitcnt vmcnt(0) retires them with the tile they belong to.
+    float pm[MODE == WS_VPROJ ? M_ : 1], pm_next[MODE == WS_VPROJ ? M_ : 1];
+    auto load_probs = [&](int64_t o0, float* dst) {
+        if (MODE == WS_VPROJ) {
+            const int64_t b = (o0 + r16) < o_end ? (o0 + r16) : (o_end - 1);
+            const float* pp = p.probs + (b * H + head) * M_;
+#pragma unroll
+            for (int m = 0; m < M_; ++m)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(dst[m]) : "v"(pp + m) : "memory");
+        }
+    };
     issue(o_beg, 0);
+    load_probs(o_beg, pm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < (MODE == WS_VPROJ ? M_ : 1); ++m) asm volatile("" : "+v"(pm[m]));
     int cur = 0;
     for (int64_t o0 = o_beg; o0 < o_end; o0 += OROWS, cur ^= 1) {
         __builtin_amdgcn_s_barrier();                              // tile visible to all waves; other buffer free
         if (o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);
-        float pm[MODE == WS_VPROJ ? M_ : 1];
-        if (MODE == WS_VPROJ) {                                   // this lane's sample: weights of the wave's head
-            const int64_t b = o0 + r16;
-#pragma unroll
-            for (int m = 0; m < M_; ++m) pm[m] = b < o_end ? p.probs[(b * H + head) * M_ + m] : 0.f;
-        }
+        if (o0 + OROWS < o_end) load_probs(o0 + OROWS, pm_next);
 
-        f32x4 acc[RT][2];
+        // ---- products.  One "item" = one LDS operand read + the 2 MFMAs it feeds (the wave's two 16-column tiles).
+        //      PLAIN: items run k-major over the two row tiles (4 independent accumulators); VPROJ: modality-major,
+        //      so only one modality's accumulators are live and V_m / o are finished as each modality completes.
+        //      The operand reads run PF items ahead of the MFMAs (a ring of PF+1 registers sets, pinned with
+        //      sched_group_barrier so the compiler keeps the reads early instead of sinking them next to their use).
+        constexpr int NIT = RT * KT;
+        constexpr int PF = 3;
+        const char* tb = smem + cur * TILE;
+        auto rd = [&](int i) -> u32x4 {
+            const int ks = MODE == WS_PLAIN ? i / RT : i % KT;
+            const int t = MODE == WS_PLAIN ? i % RT : i / KT;
+            const int toff = (MODE == WS_PLAIN ? 16 * t * ROWB : t * ROWB) + (ks >> 2) * 256;
+            return *reinterpret_cast<const u32x4*>(tb + xaddr[ks & 3] + toff);
+        };
+        constexpr int NACC = MODE == WS_PLAIN ? RT : 1;
+        f32x4 acc[NACC][2];
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
+        for (int t = 0; t < NACC; ++t)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* tb = smem + cur * TILE;
+        float ov[8];
+        u32x4 vpk[MODE == WS_VPROJ ? M_ : 1];
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
+        for (int j = 0; j < 8; ++j) ov[j] = 0.f;
+
+        u32x4 xf[PF + 1];
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const int toff = (MODE == WS_PLAIN ? 16 * t * ROWB : t * ROWB) + (ks >> 2) * 256;
-                const u32x4 xf = *reinterpret_cast<const u32x4*>(tb + xaddr[ks & 3] + toff);
+        for (int i = 0; i < PF; ++i) xf[i] = rd(i);
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);        // the PF reads of the ring's head go first
 #pragma unroll
-                for (int c = 0; c < 2; ++c) acc[t][c] = X::mma(wreg[ks][c], xf, acc[t][c]);
+        for (int i = 0; i < NIT; ++i) {
+            if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
+            const int ks = MODE == WS_PLAIN ? i / RT : i % KT;
+            const int t = MODE == WS_PLAIN ? i % RT : 0;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[t][c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[t][c]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // 2 MFMA
+            if (MODE == WS_VPROJ && ks == KT - 1) {                // modality m = i / KT is complete
+                const int m = i / KT;
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[4 * c + r] = acc[0][c][r] + bias[4 * c + r];
+                        ov[4 * c + r] = fmaf(pm[m], v[4 * c + r], ov[4 * c + r]);
+                    }
+                vpk[m] = X::pack(v);
+                acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tile landed (see above)
-        // ---- epilogue: lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + r (c = 0,1; r = 0..3) of row / sample r16
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tile (and its probabilities) landed
+#pragma unroll
+        for (int m = 0; m < (MODE == WS_VPROJ ? M_ : 1); ++m) {
+            asm volatile("" : "+v"(pm_next[m]));
+            pm[m] = pm_next[m];
+        }
+        // ---- stores: lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + r (c = 0,1; r = 0..3) of row / sample r16
         if (MODE == WS_PLAIN) {
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
@@ -152,25 +209,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
             }
         } else {
             const int64_t b = o0 + r16;
-            float ov[8];
+            if (b < o_end) {
+                if (p.v_out) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = 0.f;
-#pragma unroll
-            for (int m = 0; m < M_; ++m) {
-                float v[8];
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[4 * c + r] = acc[m][c][r] + bias[4 * c + r];
-                        ov[4 * c + r] = fmaf(pm[m], v[4 * c + r], ov[4 * c + r]);
-                    }
-                if (p.v_out && b < o_end)
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.v_out) + (b * M_ + m) * N + ncol0 + 8 * lg) =
-                        X::pack(v);
-            }
-            if (b < o_end)
+                    for (int m = 0; m < M_; ++m)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.v_out) + (b * M_ + m) * N + ncol0 + 8 * lg) =
+                            vpk[m];
+                }
                 *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + 8 * lg) = X::pack(ov);
+            }
         }
     }
 }
@@ -188,11 +235,11 @@ void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     int64_t rpb = (a.R + chunks - 1) / chunks;
     rpb = (rpb + OROWS - 1) / OROWS * OROWS;
     const int64_t nchunk = (a.R + rpb - 1) / rpb;
-    dim3 grid((unsigned)groups, (unsigned)nchunk), block(512);
+    dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
     auto kern = gemm_ws_kernel<KT, MODE, M_>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    kern<<<grid, block, smem, s>>>(a, (int)rpb);
+    kern<<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
 }
 
 template <int MODE, int M_>
