@@ -76,7 +76,7 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     w.u_slab = off; off = align_up(off + (size_t)w.u_splits * HPAD * E * 4);
     w.u = off;      off = align_up(off + HPAD * E * 4);
     w.dqp = off;    off = align_up(off + E * 4);
-    w.dq_part = off; off = align_up(off + (E / 64) * E * 4);
+    w.dq_part = off; off = align_up(off + (E / 16) * E * 4);
     w.total = off;
     return w;
 }
@@ -171,8 +171,8 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
 
     void** ev = a->stage_events;
     mark(ev, 0, s);
-    launch_prep_qs(d->dtype, a->w_in, a->b_in, a->query, qs, E, scale, s);
-    launch_prep_amat(d->dtype, a->w_in, qs, a_f32, a_hi, a_lo, E, H, s);
+    launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, a_hi, a_lo, nullptr, nullptr, nullptr, nullptr,
+                    E, H, s);
     mark(ev, 1, s);
 
     GateArgs g;
@@ -226,10 +226,8 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
 
     void** ev = a->stage_events;
     mark(ev, 0, s);
-    launch_prep_qs(d->dtype, a->w_in, a->b_in, a->query, qs, E, scale, s);
-    launch_prep_amat(d->dtype, a->w_in, qs, a_f32, ws + L.a_hi, ws + L.a_lo, E, H, s);
-    launch_transpose(d->dtype, w_v, wvt, E, s);
-    launch_transpose(d->dtype, a->w_out, wot, E, s);
+    launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, ws + L.a_hi, ws + L.a_lo, w_v, wvt, a->w_out, wot,
+                    E, H, s);
     mark(ev, 1, s);
 
     // do = dy W_o   (NT GEMM against W_o^T)

@@ -2,7 +2,7 @@
 // rank-1 / matvec parameter gradients of the query and key projections.
 //
 //   dW_o, db_o, dW_v, db_v, u  <- sum over batch splits of the gemm_tn slabs        reduce_segments (1 launch)
-//   dq'[j]   = scale * W_k[j,:] . u[h(j)]                                            fin_dqp
+//   dq'[j]   = scale * W_k[j,:] . u[h(j)]                                            fin_outer (per block)
 //   dW_q     = dq' (x) q ;  dW_k[j,:] = qs[j] * u[h(j)] ;  db_q = dq' ;  db_k = 0    fin_outer (+ dquery partials)
 //   dquery   = W_q^T dq'                                                             fin_dquery
 // db_k is exactly zero: dK = ds (x) qs and every softmax-backward row of ds sums to zero.
@@ -47,56 +47,52 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs r) {
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void fin_dqp_kernel(FinalizeArgs p) {   // wave per j
-    using X = Tr<T>;
-    const int j = blockIdx.x * 4 + wave_id();
-    if (j >= p.E) return;
-    const int lane = lane_id();
-    const typename X::elem* wk = reinterpret_cast<const typename X::elem*>(p.w_in) + (int64_t)p.E * p.E;
-    const float* u = p.u + (int64_t)(j / p.hd) * p.E;
-    float a = 0.f;
-    for (int k = lane; k < p.E; k += 64) a += X::to_f32(wk[(int64_t)j * p.E + k]) * u[k];
-    a = reduce_wave(a);
-    if (lane == 0) p.dqp[j] = a * p.scale;
-}
-
-// grid (E/64 k-blocks, E/64 j-blocks); 256 threads = 64 k x 4 j-groups, 16 j per thread
+// dq'[j] = scale * W_k[j,:] . u[h(j)]  for the 16 rows j of this block (wave per 4 rows), then
+// dW_q[j][k] = dq'[j] q[k], dW_k[j][k] = qs[j] u[h(j)][k], db_q = dq', db_k = 0 and the dquery partial
+// sum_j dq'[j] W_q[j][k] of these 16 rows.  grid (E/64 k-blocks, E/16 j-blocks); 256 threads = 64 k x 4 j-groups.
 template <typename T>
 __global__ __launch_bounds__(256) void fin_outer_kernel(FinalizeArgs p) {
     using X = Tr<T>;
     __shared__ float red[4][64];
+    __shared__ float dql[16];
     const int E = p.E;
     const int k = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int jg = threadIdx.x >> 6;
+    const int jg = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int jb = blockIdx.y;
     const typename X::elem* wq = reinterpret_cast<const typename X::elem*>(p.w_in);
+    const typename X::elem* wk = wq + (int64_t)E * E;
+    for (int jj = jg; jj < 16; jj += 4) {
+        const int j = jb * 16 + jj;
+        const float* u = p.u + (int64_t)(j / p.hd) * E;
+        float a = 0.f;
+        for (int kk = lane; kk < E; kk += 64) a += X::to_f32(wk[(int64_t)j * E + kk]) * u[kk];
+        a = reduce_wave(a);
+        if (lane == 0) dql[jj] = a * p.scale;
+    }
+    __syncthreads();
     const float qk = X::to_f32(reinterpret_cast<const typename X::elem*>(p.query)[k]);
     float part = 0.f;
-    for (int jj = jg; jj < 64; jj += 4) {
-        const int j = jb * 64 + jj;
-        const float dq = p.dqp[j];
+    for (int jj = jg; jj < 16; jj += 4) {
+        const int j = jb * 16 + jj;
+        const float dq = dql[jj];
         store_grad(p.dw_in, (int64_t)j * E + k, dq * qk, p.grad_bf16);                                         // dW_q
         store_grad(p.dw_in, (int64_t)(E + j) * E + k, p.qs[j] * p.u[(int64_t)(j / p.hd) * E + k], p.grad_bf16);   // dW_k
         part = fmaf(dq, X::to_f32(wq[(int64_t)j * E + k]), part);
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        if (blockIdx.x == 0 && lane == 0) {
             store_grad(p.db_in, j, dq, p.grad_bf16);         // db_q
             store_grad(p.db_in, E + j, 0.f, p.grad_bf16);    // db_k
         }
     }
-    red[jg][threadIdx.x & 63] = part;
+    red[jg][lane] = part;
     __syncthreads();
-    if (jg == 0) {
-        const int t = threadIdx.x;
-        p.dq_part[(int64_t)jb * E + k] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-    }
+    if (jg == 0) p.dq_part[(int64_t)jb * E + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 __global__ __launch_bounds__(256) void fin_dquery_kernel(FinalizeArgs p) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= p.E) return;
     float a = 0.f;
-    for (int jb = 0; jb < p.E / 64; ++jb) a += p.dq_part[(int64_t)jb * p.E + k];
+    for (int jb = 0; jb < p.E / 16; ++jb) a += p.dq_part[(int64_t)jb * p.E + k];
     store_grad(p.dquery, k, a, p.grad_bf16);
 }
 
@@ -109,11 +105,9 @@ void launch_reduce_segments(const ReduceSegs& r, hipStream_t s) {
 void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s) {
     const int E = a.E;
     if (dtype == 0) {
-        fin_dqp_kernel<BF16><<<dim3((E + 3) / 4), dim3(256), 0, s>>>(a);
-        fin_outer_kernel<BF16><<<dim3(E / 64, E / 64), dim3(256), 0, s>>>(a);
+        fin_outer_kernel<BF16><<<dim3(E / 64, E / 16), dim3(256), 0, s>>>(a);
     } else {
-        fin_dqp_kernel<F32><<<dim3((E + 3) / 4), dim3(256), 0, s>>>(a);
-        fin_outer_kernel<F32><<<dim3(E / 64, E / 64), dim3(256), 0, s>>>(a);
+        fin_outer_kernel<F32><<<dim3(E / 64, E / 16), dim3(256), 0, s>>>(a);
     }
     fin_dquery_kernel<<<dim3((E + 255) / 256), dim3(256), 0, s>>>(a);
 }

@@ -19,6 +19,10 @@ void launch_prep_amat(int dtype, const void* w_in, const float* qs, float* a_f32
                       hipStream_t s);
 // dst[k][j] = src[j][k]   (E x E, dtype)
 void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t s);
+// qs, folded key matrix (f32 + hi/lo) and up to two E x E transposes (t_src* may be null) in one launch
+void launch_prep_all(int dtype, const void* w_in, const void* b_in, const void* query, float scale, float* qs, float* a_f32,
+                     void* a_hi, void* a_lo, const void* t_src0, void* t_dst0, const void* t_src1, void* t_dst1, int E,
+                     int H, hipStream_t s);
 
 struct GateArgs {
     const void* x;            // [B,M,E]

@@ -70,6 +70,88 @@ __global__ __launch_bounds__(256) void transpose_kernel(const typename Tr<T>::el
     for (int r = ty; r < 32; r += 8) dst[(int64_t)(k0 + r) * E + j0 + tx] = tile[tx][r];
 }
 
+// All parameter-only preparation in ONE launch (each tiny kernel costs ~5 us of launch/drain on this part):
+//   blocks [0, nA): the folded key matrix A[h][k] = sum_{j in head h} qs[j] W_k[j][k]; each block first forms the
+//                   hd values qs[j] = (W_q[j,:] . q + b_q[j]) * scale of its head in LDS (same arithmetic order as
+//                   prep_qs_kernel), the k-block 0 of each head also writes them out;
+//   blocks [nA, ..): 32x32 tile transposes of up to two E x E matrices (backward: W_v^T, W_o^T).
+template <typename T>
+__global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::elem* __restrict__ w_in,
+                                                       const typename Tr<T>::elem* __restrict__ b_in,
+                                                       const typename Tr<T>::elem* __restrict__ q, float scale,
+                                                       float* __restrict__ qs, float* __restrict__ a_f32,
+                                                       typename Tr<T>::elem* __restrict__ a_hi,
+                                                       typename Tr<T>::elem* __restrict__ a_lo,
+                                                       const typename Tr<T>::elem* __restrict__ t_src0,
+                                                       typename Tr<T>::elem* __restrict__ t_dst0,
+                                                       const typename Tr<T>::elem* __restrict__ t_src1,
+                                                       typename Tr<T>::elem* __restrict__ t_dst1, int E, int H) {
+    using X = Tr<T>;
+    typedef typename X::elem elem;
+    __shared__ float red[4][64];
+    __shared__ float qsl[1024];
+    __shared__ elem tile[32][33];
+    const int nA = (E / 64) * HPAD;
+    int id = blockIdx.x;
+    if (id < nA) {
+        const int h = id / (E / 64), kb = id % (E / 64);
+        const int k = kb * 64 + (threadIdx.x & 63);
+        const int jg = threadIdx.x >> 6;
+        const int hd = E / H;
+        float acc = 0.f;
+        if (h < H) {
+            // 4 lanes per row j: each sums a contiguous quarter of the row with 16-byte loads (all independent, so
+            // the whole head is one round of memory latency), then a 2-step butterfly
+            const int part = threadIdx.x & 3;
+            const int qlen = E / 4;                              // multiple of 16 elements
+            for (int jj = threadIdx.x >> 2; jj < hd; jj += 64) {
+                const int j = h * hd + jj;
+                const elem* wr = w_in + (int64_t)j * E + part * qlen;
+                const elem* qr = q + part * qlen;
+                float a = 0.f;
+                for (int kk = 0; kk < qlen; kk += X::EPL) {
+                    float wv[X::EPL], qv[X::EPL];
+                    X::unpack(X::load(wr + kk), wv);
+                    X::unpack(X::load(qr + kk), qv);
+#pragma unroll
+                    for (int e = 0; e < X::EPL; ++e) a = fmaf(wv[e], qv[e], a);
+                }
+                a += __shfl_xor(a, 1, 64);
+                a += __shfl_xor(a, 2, 64);
+                if (part == 0) {
+                    const float v = (a + (b_in ? X::to_f32(b_in[j]) : 0.f)) * scale;
+                    qsl[jj] = v;
+                    if (kb == 0) qs[j] = v;
+                }
+            }
+            __syncthreads();
+            const elem* wk = w_in + (int64_t)E * E;            // W_k block of the packed in_proj_weight
+            for (int j = jg; j < hd; j += 4) acc += qsl[j] * X::to_f32(wk[(int64_t)(h * hd + j) * E + k]);
+        }
+        red[jg][threadIdx.x & 63] = acc;
+        __syncthreads();
+        if (jg == 0) {
+            const int t = threadIdx.x;
+            const float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+            a_f32[h * E + k] = v;
+            const elem hi = X::from_f32(v);
+            a_hi[h * E + k] = hi;
+            if (a_lo) a_lo[h * E + k] = X::from_f32(v - X::to_f32(hi));
+        }
+        return;
+    }
+    id -= nA;
+    const int nt = (E / 32) * (E / 32);
+    const elem* src = id < nt ? t_src0 : t_src1;
+    elem* dst = id < nt ? t_dst0 : t_dst1;
+    if (id >= nt) id -= nt;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int j0 = (id / (E / 32)) * 32, k0 = (id % (E / 32)) * 32;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(int64_t)(j0 + r) * E + k0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) dst[(int64_t)(k0 + r) * E + j0 + tx] = tile[tx][r];
+}
+
 // ------------------------------------------------------------------------------------------
 // gate_fwd: scores via MFMA (x rows as the A operand, A^T as the B operand), softmax over the M
 // modalities in registers, head mean by a 16-lane butterfly, curriculum masking per sample.
@@ -198,6 +280,23 @@ void launch_prep_amat(int dtype, const void* w_in, const float* qs, float* a_f32
                                                       (unsigned short*)a_lo, E, H);
     else
         prep_amat_kernel<F32><<<grid, block, 0, s>>>((const float*)w_in, qs, a_f32, (float*)a_hi, (float*)nullptr, E, H);
+}
+
+void launch_prep_all(int dtype, const void* w_in, const void* b_in, const void* query, float scale, float* qs, float* a_f32,
+                     void* a_hi, void* a_lo, const void* t_src0, void* t_dst0, const void* t_src1, void* t_dst1, int E,
+                     int H, hipStream_t s) {
+    const int nt = (E / 32) * (E / 32);
+    dim3 grid((E / 64) * HPAD + (t_src0 ? nt : 0) + (t_src1 ? nt : 0)), block(256);
+    if (dtype == 0)
+        prep_all_kernel<BF16><<<grid, block, 0, s>>>((const unsigned short*)w_in, (const unsigned short*)b_in,
+                                                     (const unsigned short*)query, scale, qs, a_f32, (unsigned short*)a_hi,
+                                                     (unsigned short*)a_lo, (const unsigned short*)t_src0,
+                                                     (unsigned short*)t_dst0, (const unsigned short*)t_src1,
+                                                     (unsigned short*)t_dst1, E, H);
+    else
+        prep_all_kernel<F32><<<grid, block, 0, s>>>((const float*)w_in, (const float*)b_in, (const float*)query, scale, qs,
+                                                    a_f32, (float*)a_hi, (float*)nullptr, (const float*)t_src0,
+                                                    (float*)t_dst0, (const float*)t_src1, (float*)t_dst1, E, H);
 }
 
 void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t s) {
