@@ -253,7 +253,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
         launch_bwd_g(d->dtype, g2, false, s);      // no saved V (or unsupported head size): recompute W_v^T do per head
     mark(ev, 4, s);
-    launch_bwd_g(d->dtype, g2, true, s);
+    if (!(d->dtype == AECF_BF16 && launch_dx_ws(g2, s))) launch_bwd_g(d->dtype, g2, true, s);
     mark(ev, 5, s);
 
     // dW_v = do^T pooled, db_v = colsum(do), u = ds^T x

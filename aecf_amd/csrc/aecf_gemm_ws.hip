@@ -222,6 +222,234 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// dx on the same engine:   dx[b,m,k] = sum_j (probs[b,h(j),m] do[b,j]) W_v[j,k]  +  sum_h ds[b,h,m] A[h,k]
+// Rows (b,m) of the MFMA B operand are M scaled copies of the do row (the head-wise softmax weights applied on the INPUT
+// side: B*E*M multiplies instead of the B*H*E*M fused multiply-adds of weighting g_h = W_v,h^T do_h on the output
+// side), the resident A operand is W_v^T, and the key-side term rides along as KX extra K-steps: entries
+// [ds_hi(h) | ds_lo(h) | ds_hi(h)] against [A_hi[h] | A_hi[h] | A_lo[h]] (bf16 hi/lo splits, ~16 mantissa bits).
+// Per step (16 samples): DMA of the raw do rows (double buffered), a cooperative scaling pass into the swizzled
+// operand tile, two barriers, M*(KT+KX) operand reads / 2x as many MFMAs per wave, M 16-byte stores per lane.
+template <int KT, int M_, int KX>
+__global__ __launch_bounds__(512, 2) void dx_ws_kernel(BwdGArgs p, int rows_per_block, int nchunk) {
+    using X = Tr<BF16>;
+    constexpr int K = 32 * KT, ROWB = 2 * K, CPR = 4 * KT;
+    constexpr int SROWS = 16 * M_;
+    constexpr int RAW = 16 * ROWB, TILE = SROWS * ROWB;
+    constexpr int XROWB = 64 * KX;                                // bytes per row of the extra-K tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* raw = smem;                                             // [2][16][K] do rows as they are in memory
+    char* scaled = smem + 2 * RAW;                                // [16*M][K]  rows b*M+m, chunk ^ b
+    char* xtra = scaled + TILE;                                   // [16*M][32*KX] ds hi/lo entries
+    float* stage = reinterpret_cast<float*>(xtra + SROWS * XROWB);   // [2][16*H*M]: probs | ds of the current step
+
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    const int E = p.E, H = p.H, HM = p.H * M_, nst = 16 * HM;
+    unsigned int chunk_u, group_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(E / 256), chunk_u, group_u)) return;
+    const int ncol0 = (int)group_u * 256 + 32 * w;
+    const int64_t o_beg = (int64_t)chunk_u * rows_per_block;
+    const int64_t o_end = (o_beg + rows_per_block) < p.B ? (o_beg + rows_per_block) : p.B;
+    if (o_beg >= o_end) return;
+
+    // ---- resident operand: W_v^T rows (output columns) n(c,i) = ncol0 + 8 (i >> 2) + 4 c + (i & 3), plus the A entries
+    const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.wvt);
+    u32x4 wreg[KT + KX][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3);
+        const unsigned short* wr = wsrc + (int64_t)n * K + 8 * lg;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = 32 * kx + 8 * lg + j;               // entry: [0,H) A_hi, [H,2H) A_hi, [2H,3H) A_lo
+                const int h = e < H ? e : (e < 2 * H ? e - H : e - 2 * H);
+                float a = 0.f;
+                if (e < 3 * H) {
+                    a = p.a_f32[(int64_t)h * E + n];
+                    const float hi = X::to_f32(X::from_f32(a));
+                    a = e < 2 * H ? hi : a - hi;
+                }
+                v[j] = a;
+            }
+            wreg[KT + kx][c] = X::pack(v);
+        }
+    }
+
+    // operand read addresses (see gemm_ws_kernel): row r16*M + m, chunk (4 ks + lg) ^ r16
+    int xaddr[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) xaddr[v] = r16 * M_ * ROWB + ((((4 * v) + lg) ^ r16) << 4);
+    const int xxaddr = r16 * M_ * XROWB + 16 * lg;
+
+    const char* dsrc = reinterpret_cast<const char*>(p.dobuf);
+    auto issue = [&](int64_t o0, int buf) {
+        const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
+        ws_dma_rows<KT, 16, 1 << 30>(dsrc + o0 * (int64_t)ROWB, (unsigned)ROWB, ov, raw + buf * RAW);   // key 0: linear rows
+    };
+    // probabilities and score gradients of a step: [16][H][M] floats each, fetched one step ahead by inline asm loads
+    // (see gemm_ws_kernel) and parked in LDS after the end-of-step wait
+    float stg[2][2];
+    auto load_stage = [&](int64_t o0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = threadIdx.x + 512 * i;
+            const int bb = idx / HM, rem = idx - bb * HM;
+            const int64_t b = (o0 + bb) < o_end ? (o0 + bb) : (o_end - 1);
+            const float* pp = p.probs + b * HM + rem;
+            const float* dp = p.dsbuf + b * HM + rem;
+            if (idx < nst) {
+                asm volatile("global_load_dword %0, %1, off" : "=v"(stg[i][0]) : "v"(pp) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(stg[i][1]) : "v"(dp) : "memory");
+            }
+        }
+    };
+    auto park_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = threadIdx.x + 512 * i;
+            asm volatile("" : "+v"(stg[i][0]), "+v"(stg[i][1]));
+            if (idx < nst) {
+                stage[idx] = stg[i][0];
+                stage[nst + idx] = stg[i][1];
+            }
+        }
+    };
+
+    for (int i = threadIdx.x; i < SROWS * XROWB / 4; i += 512) reinterpret_cast<unsigned int*>(xtra)[i] = 0u;
+    issue(o_beg, 0);
+    load_stage(o_beg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    park_stage();
+    int cur = 0;
+    for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // raw rows + stage visible; operand tile free
+        if (o0 + 16 < o_end) {
+            issue(o0 + 16, cur ^ 1);
+            load_stage(o0 + 16);
+        }
+        // ---- scaling pass: operand row (b, m) = probs[b, head, m] * do[b, :]
+        {
+            const char* rt = raw + cur * RAW;
+#pragma unroll
+            for (int i = 0; i < (16 * CPR + 511) / 512; ++i) {
+                const int c = threadIdx.x + 512 * i;
+                if ((16 * CPR) % 512 == 0 || c < 16 * CPR) {
+                    const int b = c / CPR, pch = c - b * CPR;
+                    float v[8];
+                    X::unpack(*reinterpret_cast<const u32x4*>(rt + b * ROWB + pch * 16), v);
+                    const float* pr = stage + (b * H + (8 * pch) / p.hd) * M_;
+#pragma unroll
+                    for (int m = 0; m < M_; ++m) {
+                        const float pm = pr[m];
+                        float sv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sv[j] = pm * v[j];
+                        *reinterpret_cast<u32x4*>(scaled + (b * M_ + m) * ROWB + ((pch ^ b) << 4)) = X::pack(sv);
+                    }
+                }
+            }
+            for (int t = threadIdx.x; t < 16 * HM; t += 512) {     // (b, h, m): hi/lo entries of ds
+                const int b = t / HM, rem = t - b * HM, h = rem / M_, m = rem - h * M_;
+                const float d = stage[nst + t];
+                const unsigned short hi = X::from_f32(d);
+                const unsigned short lo = X::from_f32(d - X::to_f32(hi));
+                unsigned short* xr = reinterpret_cast<unsigned short*>(xtra + (b * M_ + m) * XROWB);
+                xr[h] = hi;
+                xr[H + h] = lo;
+                xr[2 * H + h] = hi;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // operand tile visible
+
+        // ---- products, modality-major (one accumulator pair live), reads PF items ahead (see gemm_ws_kernel)
+        constexpr int KK = KT + KX, NIT = M_ * KK, PF = 3;
+        auto rd = [&](int i) -> u32x4 {
+            const int m = i / KK, ks = i % KK;
+            if (ks < KT) return *reinterpret_cast<const u32x4*>(scaled + xaddr[ks & 3] + m * ROWB + (ks >> 2) * 256);
+            return *reinterpret_cast<const u32x4*>(xtra + xxaddr + m * XROWB + (ks - KT) * 64);
+        };
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        u32x4 vpk[M_];
+        u32x4 xf[PF + 1];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) xf[i] = rd(i);
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
+            const int ks = i % KK;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[c]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (ks == KK - 1) {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[c][r];
+                vpk[i / KK] = X::pack(v);
+                acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next raw rows + stage values landed
+        if (o0 + 16 < o_end) park_stage();
+        const int64_t b = o0 + r16;
+        if (b < o_end) {
+#pragma unroll
+            for (int m = 0; m < M_; ++m)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.dx) + (b * M_ + m) * E + ncol0 + 8 * lg) = vpk[m];
+        }
+    }
+}
+
+template <int KT, int M_, int KX>
+void launch_dx(const BwdGArgs& a, hipStream_t s) {
+    constexpr int K = 32 * KT;
+    const size_t smem = (size_t)2 * 16 * 2 * K + (size_t)16 * M_ * 2 * K + (size_t)16 * M_ * 64 * KX +
+                        (size_t)2 * 16 * a.H * M_ * sizeof(float);
+    const int groups = a.E / 256;
+    int64_t chunks = 256 / groups;
+    if (chunks < 1) chunks = 1;
+    int64_t rpb = (a.B + chunks - 1) / chunks;
+    rpb = (rpb + 15) / 16 * 16;
+    const int64_t nchunk = (a.B + rpb - 1) / rpb;
+    dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
+    auto kern = dx_ws_kernel<KT, M_, KX>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
+}
+
+template <int M_, int KX>
+void launch_dx_kt(const BwdGArgs& a, hipStream_t s) {
+    switch (a.E / 32) {
+        case 4: launch_dx<4, M_, KX>(a, s); break;
+        case 8: launch_dx<8, M_, KX>(a, s); break;
+        case 12: launch_dx<12, M_, KX>(a, s); break;
+        default: launch_dx<16, M_, KX>(a, s); break;
+    }
+}
+
+template <int KX>
+void launch_dx_m(const BwdGArgs& a, hipStream_t s) {
+    switch (a.M) {
+        case 1: launch_dx_kt<1, KX>(a, s); break;
+        case 2: launch_dx_kt<2, KX>(a, s); break;
+        case 3: launch_dx_kt<3, KX>(a, s); break;
+        default: launch_dx_kt<4, KX>(a, s); break;
+    }
+}
+
 template <int KT, int MODE, int M_>
 void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
@@ -273,6 +501,16 @@ void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s) {
     } else {
         launch_kt<WS_PLAIN, 1>(a, s);
     }
+}
+
+// dx through the weight-stationary engine (bf16); false = shape not taken (caller uses launch_bwd_g(dx = true))
+bool launch_dx_ws(const BwdGArgs& a, hipStream_t s) {
+    static const int no_ws = getenv("AECF_NO_WS") ? atoi(getenv("AECF_NO_WS")) : 0;
+    if (no_ws) return false;
+    if (a.E % 128 != 0 || a.E < 256 || a.E > 512 || a.E % 256 != 0) return false;
+    if (a.M < 1 || a.M > 4 || a.hd % 8 != 0 || 16 * a.H * a.M > 1024) return false;
+    if (3 * a.H <= 32) launch_dx_m<1>(a, s); else launch_dx_m<2>(a, s);
+    return true;
 }
 
 }  // namespace aecf

@@ -90,6 +90,7 @@ void launch_bwd_g(int dtype, const BwdGArgs& a, bool dx, hipStream_t s);
 // score gradient from the saved value projections: da[b,h,m] = do_h[b] . V_h[b,m]  (memory-bound, one wave per sample)
 // returns false when the head size is not supported by this kernel (caller falls back to launch_bwd_g(dx = false))
 bool launch_dscore_v(int dtype, const BwdGArgs& a, const void* saved_v, hipStream_t s);
+bool launch_dx_ws(const BwdGArgs& a, hipStream_t s);        // bf16 dx on the weight-stationary engine (aecf_gemm_ws.hip)
 
 // out[split][j][k] = sum_{b in split} lhs[b][j] * rhs(b,k)        (f32 partial slabs, deterministic)
 //   pooled == 0: rhs(b,k) = rhs[b*E + k]

@@ -20,6 +20,10 @@ SHAPES = [
     (129, 3, 256, 16),    # 16 heads (head_dim 16: fp32 only)
     (200, 3, 512, 2),     # head_dim 256
     (513, 6, 64, 1),
+    (96, 2, 512, 16),     # 16 heads of 32: two extra K-steps of the key-side term in the weight-stationary dx kernel
+    (50, 4, 512, 4),      # M = 4: the largest modality count the weight-stationary kernels take
+    (33, 1, 256, 4),      # E = 256 (one column group), a single modality
+    (1100, 3, 512, 8),    # several row chunks per column group, ragged last step
 ]
 
 
