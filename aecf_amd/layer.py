@@ -64,6 +64,7 @@ class _PoolFunction(torch.autograd.Function):
     def forward(ctx, x, q, w_in, b_in, w_out, b_out, kpm, uniforms, num_heads, mask_mode, min_active,
                 base_mask_prob, entropy_target, eps, f32_info=False):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)       # unused outputs arrive as None, not as zero tensors (fill + cast launches)
         B, M, E = x.shape
         dt = x.dtype
         desc = _lib.PoolDesc(B, M, E, num_heads, _DTYPES[dt], mask_mode, min_active, base_mask_prob,
@@ -170,6 +171,7 @@ class _MaskFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, uniforms, mode, min_active, base_mask_prob, entropy_target, eps):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)
         L = weights.shape[-1]
         rows = weights.numel() // L
         w32 = weights.detach().to(torch.float32).contiguous()

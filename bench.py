@@ -122,7 +122,7 @@ def stage_model(cfg):
     s = 2 if dtype == torch.bfloat16 else 4
     return {
         "fwd.gate":    dict(bytes=s * M * E, flops=2 * M * E * 16 * (2 if s == 2 else 1)),
-        "fwd.vproj":   dict(bytes=s * (M + 1) * E, flops=2 * M * E * E),      # one accumulator set per modality
+        "fwd.vproj":   dict(bytes=s * (2 * M + 1) * E, flops=2 * M * E * E),  # reads x, writes V (kept for the backward) and o
         "fwd.outproj": dict(bytes=s * 2 * E, flops=2 * E * E),
         "bwd.dout":    dict(bytes=s * 2 * E, flops=2 * E * E),
         "bwd.dw_out":  dict(bytes=s * 2 * E, flops=2 * E * E),
@@ -236,7 +236,7 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
         # corrected as MI355X_MICROARCH.md prescribes); null when no counter pass exists for this config
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"r01_v2_{args.config}_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", f"r01_v4_{args.config}_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f)["bytes_per_launch"].get(dom)
