@@ -61,13 +61,25 @@ __global__ __launch_bounds__(256) void fin_outer_kernel(FinalizeArgs p) {
     const int jb = blockIdx.y;
     const typename X::elem* wq = reinterpret_cast<const typename X::elem*>(p.w_in);
     const typename X::elem* wk = wq + (int64_t)E * E;
-    for (int jj = jg; jj < 16; jj += 4) {
+    {   // 16 threads per row j: contiguous E/16-element pieces (16-byte loads, all independent), 4-step butterfly
+        const int jj = threadIdx.x >> 4, part = threadIdx.x & 15;
         const int j = jb * 16 + jj;
-        const float* u = p.u + (int64_t)(j / p.hd) * E;
+        const int plen = E / 16;                                   // multiple of 4 (E % 64 == 0)
+        const float* u = p.u + (int64_t)(j / p.hd) * E + part * plen;
+        const typename X::elem* wr = wk + (int64_t)j * E + part * plen;
         float a = 0.f;
-        for (int kk = lane; kk < E; kk += 64) a += X::to_f32(wk[(int64_t)j * E + kk]) * u[kk];
-        a = reduce_wave(a);
-        if (lane == 0) dql[jj] = a * p.scale;
+        for (int kk = 0; kk < plen; kk += 4) {
+            float wv[4];
+            X::load4(wr + kk, wv);
+            const f32x4 uv = *reinterpret_cast<const f32x4*>(u + kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = fmaf(wv[e], uv[e], a);
+        }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        a += __shfl_xor(a, 8, 64);
+        if (part == 0) dql[jj] = a * p.scale;
     }
     __syncthreads();
     const float qk = X::to_f32(reinterpret_cast<const typename X::elem*>(p.query)[k]);
@@ -88,10 +100,11 @@ __global__ __launch_bounds__(256) void fin_outer_kernel(FinalizeArgs p) {
     if (jg == 0) p.dq_part[(int64_t)jb * E + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
-__global__ __launch_bounds__(256) void fin_dquery_kernel(FinalizeArgs p) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void fin_dquery_kernel(FinalizeArgs p) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= p.E) return;
     float a = 0.f;
+#pragma unroll 8
     for (int jb = 0; jb < p.E / 16; ++jb) a += p.dq_part[(int64_t)jb * p.E + k];
     store_grad(p.dquery, k, a, p.grad_bf16);
 }
@@ -109,7 +122,7 @@ void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s) {
     } else {
         fin_outer_kernel<F32><<<dim3(E / 64, E / 16), dim3(256), 0, s>>>(a);
     }
-    fin_dquery_kernel<<<dim3((E + 255) / 256), dim3(256), 0, s>>>(a);
+    fin_dquery_kernel<<<dim3((E + 63) / 64), dim3(64), 0, s>>>(a);
 }
 
 }  // namespace aecf
