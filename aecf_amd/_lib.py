@@ -90,6 +90,7 @@ _SYMBOLS = [
     ("aecf_sdpa_backward", c_int,
      [c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("aecf_modality_frontend", c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_l2norm_forward", c_int, [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_l2norm_backward", c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_nce_workspace_bytes", c_size_t, [c_int64, c_int64, c_int32, c_int32]),

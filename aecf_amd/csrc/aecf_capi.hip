@@ -345,6 +345,15 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
     return launch_status();
 }
 
+int aecf_modality_frontend(int64_t rows, int32_t dim, int32_t dtype, const void* feat, const uint8_t* drop, void* out,
+                           uint8_t* present, void* stream) {
+    if (rows <= 0 || dim <= 0) return AECF_ERR_BAD_DIMS;
+    if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (!feat || !present || (drop && !out)) return AECF_ERR_NULL_POINTER;
+    launch_modality_frontend(dtype, rows, dim, feat, drop, out, present, (hipStream_t)stream);
+    return launch_status();
+}
+
 int aecf_l2norm_forward(int64_t n, int32_t d, int32_t dtype, float eps, const void* z, void* zn, float* inv_norm,
                         void* stream) {
     if (n <= 0 || d <= 0) return AECF_ERR_BAD_DIMS;

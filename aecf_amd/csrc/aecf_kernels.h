@@ -167,6 +167,8 @@ void launch_l2norm_bwd(int dtype, int64_t n, int d, const void* zn, const float*
 void launch_nce_rows(int dtype, int64_t rows, int64_t cols, int64_t row_offset, float inv_temp, float coef, const float* S,
                      void* G, float* loss_rows, hipStream_t s);
 // dst[c][r] = src[r][c]   (R x C, dtype; R, C multiples of 32)
+void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat, const uint8_t* drop, void* out,
+                              uint8_t* present, hipStream_t s);
 void launch_transpose_rect(int dtype, const void* src, void* dst, int64_t R, int64_t C, hipStream_t s);
 
 }  // namespace aecf

@@ -247,6 +247,54 @@ void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, cons
     else mask_bwd_kernel<32><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
 }
 
+// ------------------------------------------------------------------------------------------
+// missing-modality front-end (ref xrays/train_xrays_example.py:156-177, 202-203): one wave per feature row; the row is
+// read once, its squared norm reduced in float32, and written zeroed or as is.
+template <typename T>
+__global__ __launch_bounds__(256) void modality_frontend_kernel(int64_t rows, int dim, const typename Tr<T>::elem* __restrict__ feat,
+                                                                const uint8_t* __restrict__ drop,
+                                                                typename Tr<T>::elem* out, uint8_t* __restrict__ present) {
+    using X = Tr<T>;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave_id();
+    if (r >= rows) return;
+    const int lane = lane_id();
+    const bool dropped = drop && drop[r] != 0;
+    const typename X::elem* src = feat + r * dim;
+    typename X::elem* dst = out ? out + r * dim : nullptr;
+    float ss = 0.f;
+    const bool vec = (dim % X::EPL == 0) && ((reinterpret_cast<uintptr_t>(feat) | (out ? reinterpret_cast<uintptr_t>(out) : 0)) % 16 == 0);
+    if (vec) {
+        for (int c = lane * X::EPL; c < dim; c += 64 * X::EPL) {
+            typename X::frag v = X::load(src + c);
+            if (dropped) v = X::zero();
+            float f[X::EPL];
+            X::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < X::EPL; ++e) ss = fmaf(f[e], f[e], ss);
+            if (dst && (dropped || dst != src)) *reinterpret_cast<typename X::frag*>(dst + c) = v;
+        }
+    } else {
+        for (int c = lane; c < dim; c += 64) {
+            const typename X::elem v = dropped ? X::from_f32(0.f) : src[c];
+            const float f = X::to_f32(v);
+            ss = fmaf(f, f, ss);
+            if (dst && (dropped || dst != src)) dst[c] = v;
+        }
+    }
+    ss = reduce_wave(ss);
+    if (lane == 0) present[r] = sqrtf(ss) > 1e-6f ? 1 : 0;
+}
+
+void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat, const uint8_t* drop, void* out,
+                              uint8_t* present, hipStream_t s) {
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == 0)
+        modality_frontend_kernel<BF16><<<grid, block, 0, s>>>(rows, dim, (const unsigned short*)feat, drop,
+                                                              (unsigned short*)out, present);
+    else
+        modality_frontend_kernel<F32><<<grid, block, 0, s>>>(rows, dim, (const float*)feat, drop, (float*)out, present);
+}
+
 void launch_entropy_loss(int dtype, int64_t n, float target, const void* entropy, float upstream, void* loss,
                          float* d_entropy, float* partial, hipStream_t s) {
     int nblk = (int)((n + 255) / 256);

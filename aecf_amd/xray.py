@@ -14,8 +14,30 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .layer import CurriculumMasking, MultimodalAttentionPool
-from . import dp
+from .layer import CurriculumMasking, MultimodalAttentionPool, _DTYPES, _ptr, _stream
+from . import _lib, dp
+
+
+def modality_frontend(features: torch.Tensor, drop: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Missing-modality front-end of one modality in ONE kernel pass: rows with
+    ``drop[r]`` set are zeroed (the reference's ``clone()`` + masked write, ``xrays/train_xrays_example.py:173-176``)
+    and ``present[r] = ||row|| > 1e-6`` of the row as written (the reference's presence test, ``:202-203``).
+    Returns ``(features_out, present_bool)``; without ``drop`` the input tensor itself is returned (no copy).
+    Features are data (the reference feeds precomputed CLIP embeddings): no gradient flows to them."""
+    if features.device.type != "cuda":
+        raise RuntimeError("aecf_amd: the HIP path needs tensors on a ROCm device (no CPU fallback is provided)")
+    if features.dim() != 2 or features.dtype not in _DTYPES:
+        raise ValueError("modality_frontend expects a [rows, dim] float32 or bfloat16 tensor")
+    lib = _lib.load()
+    f = features.detach().contiguous()
+    rows, dim = f.shape
+    present = torch.empty(rows, dtype=torch.uint8, device=f.device)
+    d8 = None if drop is None else drop.to(device=f.device, dtype=torch.uint8).contiguous()
+    out = f if drop is None else torch.empty_like(f)
+    _lib.check(lib.aecf_modality_frontend(rows, dim, _DTYPES[f.dtype], _ptr(f), _ptr(d8),
+                                          None if drop is None else _ptr(out), _ptr(present), _stream()),
+               "aecf_modality_frontend")
+    return out, present.bool()
 
 
 class AECFModel(nn.Module):
@@ -40,9 +62,10 @@ class AECFModel(nn.Module):
                                         nn.Linear(hidden_dim, num_classes))
 
     def _simulate_missing_modalities(self, image_features, text_features, missing_prob: float = 0.3):
-        """ref :156-177 -- random modality zeroing, never both."""
+        """ref :156-172 -- which rows lose which modality (never both); same RNG consumption as the reference.
+        The zeroing itself (:173-176) happens in ``modality_frontend`` together with the presence test."""
         if not (self.training and self.missing_modality_training):
-            return image_features, text_features
+            return None, None
         batch_size = image_features.size(0)
         mask_image = torch.rand(batch_size, device=image_features.device) < missing_prob
         mask_text = torch.rand(batch_size, device=text_features.device) < missing_prob
@@ -51,11 +74,7 @@ class AECFModel(nn.Module):
             keep_image = torch.rand(int(both_masked.sum()), device=image_features.device) > 0.5
             mask_image[both_masked] = ~keep_image
             mask_text[both_masked] = keep_image
-        masked_image = image_features.clone()
-        masked_text = text_features.clone()
-        masked_image[mask_image] = 0
-        masked_text[mask_text] = 0
-        return masked_image, masked_text
+        return mask_image, mask_text
 
     def toggle_curriculum(self, enabled: bool) -> None:
         """ref :179-187 (without the prints)."""
@@ -66,12 +85,11 @@ class AECFModel(nn.Module):
         """ref :189-237."""
         batch_size = image_features.size(0)
         info: Dict[str, torch.Tensor] = {}
-        if self.training and self.missing_modality_training:
-            image_features, text_features = self._simulate_missing_modalities(image_features, text_features)
+        drop_img, drop_txt = self._simulate_missing_modalities(image_features, text_features)
+        image_features, img_present = modality_frontend(image_features, drop_img)          # ref :173-176 + :202
+        text_features, txt_present = modality_frontend(text_features, drop_txt)           # ref :173-176 + :203
         img_encoded = self.image_encoder(image_features)
         txt_encoded = self.text_encoder(text_features)
-        img_present = torch.norm(image_features, dim=1) > 1e-6                  # ref :202-203
-        txt_present = torch.norm(text_features, dim=1) > 1e-6
         both_present = img_present & txt_present
         only_img = img_present & ~txt_present
         only_txt = ~img_present & txt_present

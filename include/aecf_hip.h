@@ -176,6 +176,14 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
                        const void* q, const void* k, const void* v, const float* probs,
                        const void* dout, void* dq, void* dk, void* dv, void* stream);
 
+/* ---- missing-modality front-end (ref xrays/train_xrays_example.py:156-177, 202-203) ----
+ * One pass over one modality's feature rows feat [rows,dim]: rows with drop[r] != 0 are zeroed (the reference's
+ * clone + masked write, :173-176) and present[r] = (||row||_2 > 1e-6) of the row AS WRITTEN (the reference's
+ * torch.norm(...) > 1e-6 presence test, :202-203).  drop may be NULL (evaluation: presence only); out may equal
+ * feat (in place) and may be NULL when drop is NULL (nothing to write).  Norm accumulated in float32. */
+int aecf_modality_frontend(int64_t rows, int32_t dim, int32_t dtype, const void* feat, const uint8_t* drop,
+                           void* out, uint8_t* present, void* stream);
+
 /* ---- contrastive term (BASELINE.json north_star; NOT in the reference: SURVEY.md 8a row A9, build-defined) ----
  * Row-wise L2 normalisation zn = z / max(||z||, eps) and its backward dz = (dzn - zn (dzn.zn)) * inv_norm. */
 int aecf_l2norm_forward(int64_t n, int32_t d, int32_t dtype, float eps, const void* z, void* zn,

@@ -410,3 +410,49 @@ def test_train_step_runs_and_learns():
     assert losses[-1] < 0.8 * losses[0], losses
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     assert info["mask_rate"].dtype == torch.float32 and "target_entropy" in info
+
+
+def test_modality_frontend_matches_reference_ops():
+    """zeroing + presence test in one pass == the reference's clone / masked write / norm test
+    (xrays/train_xrays_example.py:173-176, 202-203), bit for bit, for float32 and bfloat16 features, odd widths,
+    naturally-absent (all-zero) rows and sub-threshold rows."""
+    from aecf_amd.xray import modality_frontend
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    for dtype in (torch.float32, torch.bfloat16):
+        for rows, dim in ((1, 512), (257, 512), (64, 100), (33, 7)):
+            f = torch.randn(rows, dim, generator=g).to(dtype)
+            f[rows // 2] = 0                                     # a modality that is absent in the data
+            if rows > 3:
+                f[3] = 1e-9                                      # below the 1e-6 norm threshold
+            drop = torch.rand(rows, generator=g) < 0.3
+            want = f.clone()
+            want[drop] = 0
+            want_present = torch.norm(want.float(), dim=1) > 1e-6
+            out, present = modality_frontend(f.to(dev), drop.to(dev))
+            assert torch.equal(out.cpu(), want) and torch.equal(present.cpu(), want_present), (dtype, rows, dim)
+            out2, present2 = modality_frontend(f.to(dev), None)  # evaluation: presence only, no copy
+            assert torch.equal(out2.cpu(), f) and torch.equal(present2.cpu(), torch.norm(f.float(), dim=1) > 1e-6)
+
+
+def test_model_missing_modality_training_routes_like_reference_ops():
+    """AECFModel with missing_modality_training: same RNG consumption and the same routing decisions as the reference's
+    ops (drop masks from the same torch.rand calls; presence from the zeroed rows)."""
+    from aecf_amd.xray import AECFModel
+    dev = _dev()
+    torch.manual_seed(5)
+    model = AECFModel(64, 48, 5, 64).to(dev).train()
+    model.missing_modality_training = True
+    model.toggle_curriculum(True)
+    img, txt = torch.randn(300, 64, device=dev), torch.randn(300, 48, device=dev)
+    torch.manual_seed(9)
+    di, dt_ = model._simulate_missing_modalities(img, txt)
+    assert not bool((di & dt_).any()) and 0.15 < float(di.float().mean()) < 0.45
+    state = torch.cuda.get_rng_state(dev)
+    torch.manual_seed(9)
+    logits, info = model(img, txt, return_info=True)
+    both = int((~di & ~dt_).sum())
+    assert logits.shape == (300, 5) and info["attention_weights"].shape == (both, 1, 2)
+    assert torch.isfinite(logits).all()
+    logits.sum().backward()
+    assert model.fusion_query.grad is not None and torch.isfinite(model.fusion_query.grad).all()
