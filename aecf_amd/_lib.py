@@ -66,6 +66,27 @@ class PoolBwdArgs(Structure):
     ]
 
 
+class MhaDesc(Structure):
+    _fields_ = [("batch", c_int64), ("tgt_len", c_int32), ("src_len", c_int32), ("embed_dim", c_int32),
+                ("num_heads", c_int32), ("dtype", c_int32), ("dropout_p", c_float)]
+
+
+class MhaFwdArgs(Structure):
+    _fields_ = [("query", c_void_p), ("key", c_void_p), ("value", c_void_p), ("w_in", c_void_p), ("b_in", c_void_p),
+                ("w_out", c_void_p), ("b_out", c_void_p), ("attn_mask", c_void_p), ("attn_mask_stride", c_int64),
+                ("key_padding_mask", c_void_p), ("dropout_uniforms", c_void_p), ("y", c_void_p), ("attn_w", c_void_p),
+                ("saved_q", c_void_p), ("saved_k", c_void_p), ("saved_v", c_void_p), ("saved_o", c_void_p),
+                ("saved_probs", c_void_p)]
+
+
+class MhaBwdArgs(Structure):
+    _fields_ = [("query", c_void_p), ("key", c_void_p), ("value", c_void_p), ("w_in", c_void_p), ("w_out", c_void_p),
+                ("dropout_uniforms", c_void_p), ("dy", c_void_p), ("d_attn_w", c_void_p), ("saved_q", c_void_p),
+                ("saved_k", c_void_p), ("saved_v", c_void_p), ("saved_o", c_void_p), ("saved_probs", c_void_p),
+                ("dquery", c_void_p), ("dkey", c_void_p), ("dvalue", c_void_p), ("dw_in", c_void_p), ("db_in", c_void_p),
+                ("dw_out", c_void_p), ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
 # every symbol include/aecf_hip.h declares: (name, restype, argtypes)
 _SYMBOLS = [
     ("aecf_abi_version", c_int, []),
@@ -90,6 +111,10 @@ _SYMBOLS = [
     ("aecf_sdpa_backward", c_int,
      [c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("aecf_mha_check", c_int, [POINTER(MhaDesc)]),
+    ("aecf_mha_bwd_workspace_bytes", c_size_t, [POINTER(MhaDesc)]),
+    ("aecf_mha_forward", c_int, [POINTER(MhaDesc), POINTER(MhaFwdArgs), c_void_p]),
+    ("aecf_mha_backward", c_int, [POINTER(MhaDesc), POINTER(MhaBwdArgs), c_void_p]),
     ("aecf_modality_frontend", c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_l2norm_forward", c_int, [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_l2norm_backward", c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -232,6 +232,71 @@ class _EntropyLossFunction(torch.autograd.Function):
         return (dent * dloss.to(torch.float32)).to(ctx.edtype), None, None
 
 
+class _MhaFunction(torch.autograd.Function):
+    """aecf_mha_forward / aecf_mha_backward: the general nn.MultiheadAttention case (per-sample queries, tgt_len > 1,
+    key != value, attn_mask, key_padding_mask, dropout).  Batch-major [B,T,E] / [B,S,E].  Outputs y [B,T,E] and the
+    head-averaged (post-dropout) weights [B,T,S] float32."""
+
+    @staticmethod
+    def forward(ctx, query, key, value, w_in, b_in, w_out, b_out, attn_mask, mask_stride, kpm, drop_u, drop_p,
+                num_heads):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        B, T, E = query.shape
+        S = key.shape[1]
+        dt = query.dtype
+        dev = query.device
+        desc = _lib.MhaDesc(B, T, S, E, num_heads, _DTYPES[dt], float(drop_p))
+        _lib.check(lib.aecf_mha_check(ctypes.byref(desc)), "aecf_mha_check")
+        qc, kc, vc = query.detach().contiguous(), key.detach().to(dt).contiguous(), value.detach().to(dt).contiguous()
+        w_in_c, w_out_c = w_in.detach().to(dt).contiguous(), w_out.detach().to(dt).contiguous()
+        b_in_c = None if b_in is None else b_in.detach().to(dt).contiguous()
+        b_out_c = None if b_out is None else b_out.detach().to(dt).contiguous()
+        y = torch.empty(B, T, E, dtype=dt, device=dev)
+        attn_w = torch.empty(B, T, S, dtype=torch.float32, device=dev)
+        sq = torch.empty(B * T, E, dtype=dt, device=dev)
+        sk = torch.empty(B * S, E, dtype=dt, device=dev)
+        sv = torch.empty(B * S, E, dtype=dt, device=dev)
+        so = torch.empty(B * T, E, dtype=dt, device=dev)
+        probs = torch.empty(B, num_heads, T, S, dtype=torch.float32, device=dev)
+        args = _lib.MhaFwdArgs(_ptr(qc), _ptr(kc), _ptr(vc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(b_out_c),
+                               _ptr(attn_mask), int(mask_stride), _ptr(kpm), _ptr(drop_u), _ptr(y), _ptr(attn_w),
+                               _ptr(sq), _ptr(sk), _ptr(sv), _ptr(so), _ptr(probs))
+        _lib.check(lib.aecf_mha_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_mha_forward")
+        ctx.save_for_backward(qc, kc, vc, w_in_c, w_out_c, drop_u, sq, sk, sv, so, probs)
+        ctx.desc = desc
+        ctx.in_dtypes = (key.dtype, value.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
+                         None if b_out is None else b_out.dtype)
+        return y, attn_w
+
+    @staticmethod
+    def backward(ctx, dy, d_attn_w):
+        lib = _lib.load()
+        qc, kc, vc, w_in_c, w_out_c, drop_u, sq, sk, sv, so, probs = ctx.saved_tensors
+        desc = ctx.desc
+        B, T, E = qc.shape
+        S = kc.shape[1]
+        dt, dev = qc.dtype, qc.device
+        dy_c = torch.zeros(B, T, E, dtype=dt, device=dev) if dy is None else dy.to(dt).contiguous()
+        daw = None if d_attn_w is None else d_attn_w.to(torch.float32).contiguous()
+        dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dw_in, db_in = torch.empty(3 * E, E, **f32), torch.empty(3 * E, **f32)
+        dw_out, db_out = torch.empty(E, E, **f32), torch.empty(E, **f32)
+        ws_bytes = lib.aecf_mha_bwd_workspace_bytes(ctypes.byref(desc))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        args = _lib.MhaBwdArgs(_ptr(qc), _ptr(kc), _ptr(vc), _ptr(w_in_c), _ptr(w_out_c), _ptr(drop_u), _ptr(dy_c),
+                               _ptr(daw), _ptr(sq), _ptr(sk), _ptr(sv), _ptr(so), _ptr(probs), _ptr(dq), _ptr(dk),
+                               _ptr(dv), _ptr(dw_in), _ptr(db_in), _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes)
+        _lib.check(lib.aecf_mha_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_mha_backward")
+        kd, vd, wid, bid, wod, bod = ctx.in_dtypes
+        needs = ctx.needs_input_grad
+        return (dq if needs[0] else None, dk.to(kd) if needs[1] else None, dv.to(vd) if needs[2] else None,
+                dw_in.to(wid) if needs[3] else None, db_in.to(bid) if (bid is not None and needs[4]) else None,
+                dw_out.to(wod) if needs[5] else None, db_out.to(bod) if (bod is not None and needs[6]) else None,
+                None, None, None, None, None, None)
+
+
 class _SdpaFunction(torch.autograd.Function):
     """aecf_sdpa_forward / _backward (projection-free single-head attention, ref :556-581)."""
 
@@ -437,12 +502,6 @@ class MultimodalAttentionPool(nn.Module):
         _require_device(query, "query")
         same_kv = (value is key) or (value.data_ptr() == key.data_ptr() and value.shape == key.shape
                                      and value.stride() == key.stride())
-        if not same_kv:
-            raise NotImplementedError("aecf_amd: value must be the key tensor (modalities attend to themselves)")
-        if attn_mask is not None:
-            raise NotImplementedError("aecf_amd: attn_mask is not supported by the HIP fusion path")
-        if self.attention.dropout > 0.0 and self.training:
-            raise NotImplementedError("aecf_amd: attention dropout > 0 in training mode is not supported")
         if key.dtype not in _DTYPES:
             raise NotImplementedError(f"aecf_amd: dtype {key.dtype} is not supported (bfloat16 / float32 only)")
 
@@ -452,10 +511,11 @@ class MultimodalAttentionPool(nn.Module):
         else:
             q_bf, x = query.transpose(0, 1), key.transpose(0, 1)
         q_base = _shared_query_base(q_bf)
-        if q_base is None:
-            raise NotImplementedError(
-                "aecf_amd: the HIP path needs ONE query shared by the batch, i.e. fusion_query.expand(B, -1, -1) "
-                "with tgt_len 1 (ref aecf/AECFLayer.py:694-695)")
+        dropping = self.attention.dropout > 0.0 and self.training
+        if q_base is None or not same_kv or attn_mask is not None or dropping:
+            # everything outside the shared-query hot path: the general attention kernels
+            return self._forward_general(q_bf, x, value if self.batch_first else value.transpose(0, 1),
+                                         key_padding_mask, attn_mask, return_info, batch_size, tgt_len, src_len)
         kpm = None
         if key_padding_mask is not None:
             if key_padding_mask.shape != (batch_size, src_len):
@@ -500,6 +560,66 @@ class MultimodalAttentionPool(nn.Module):
             else:
                 mask_info = {'entropy': entropy.to(dt).unsqueeze(1), 'mask_rate': mask_rate.to(dt).unsqueeze(1)}
                 masked_weights = attn_weights
+            info.update(mask_info)
+            info['attention_weights'] = attn_weights
+            if return_info:
+                info['masked_attention_weights'] = masked_weights.detach()
+        elif return_info:
+            info['attention_weights'] = attn_weights
+        if return_info:
+            return attn_output, info
+        return attn_output
+
+    def _forward_general(self, q_bf, k_bf, v_bf, key_padding_mask, attn_mask, return_info, batch_size, tgt_len,
+                         src_len):
+        """nn.MultiheadAttention semantics for per-sample queries / tgt_len > 1 / key != value / attn_mask / dropout
+        (ref :503-521 -> torch functional.py:5836-5852, 6504-6612), then the curriculum hook exactly as the
+        reference applies it to the pooled weights (ref :526-541)."""
+        dev, dt, H = k_bf.device, k_bf.dtype, self.num_heads
+        add_mask, stride = None, 0
+        if attn_mask is not None:                                              # torch functional.py:6237-6264
+            if attn_mask.dim() == 2:
+                if tuple(attn_mask.shape) != (tgt_len, src_len):
+                    raise RuntimeError(f"The shape of the 2D attn_mask is {attn_mask.shape}, but should be "
+                                       f"{(tgt_len, src_len)}.")
+            elif attn_mask.dim() == 3:
+                if tuple(attn_mask.shape) != (batch_size * H, tgt_len, src_len):
+                    raise RuntimeError(f"The shape of the 3D attn_mask is {attn_mask.shape}, but should be "
+                                       f"{(batch_size * H, tgt_len, src_len)}.")
+                stride = tgt_len * src_len
+            else:
+                raise RuntimeError(f"attn_mask's dimension {attn_mask.dim()} is not supported")
+            am = attn_mask.to(dev)
+            if am.dtype == torch.bool:
+                add_mask = torch.zeros(am.shape, dtype=torch.float32, device=dev).masked_fill_(am, float("-inf"))
+            else:
+                add_mask = am.to(torch.float32)
+            add_mask = add_mask.contiguous()
+        kpm = None
+        if key_padding_mask is not None:
+            if tuple(key_padding_mask.shape) != (batch_size, src_len):
+                raise RuntimeError(f"key_padding_mask shape {tuple(key_padding_mask.shape)} != {(batch_size, src_len)}")
+            if key_padding_mask.dtype == torch.bool or not key_padding_mask.is_floating_point():
+                kpm = key_padding_mask.to(device=dev, dtype=torch.uint8).contiguous()
+            else:                                                              # float masks are additive in torch
+                extra = key_padding_mask.to(dev, torch.float32).view(batch_size, 1, 1, src_len)
+                base = 0.0 if add_mask is None else (add_mask.view(batch_size, H, tgt_len, src_len) if stride
+                                                     else add_mask.view(1, 1, tgt_len, src_len))
+                add_mask = (base + extra).expand(batch_size, H, tgt_len, src_len).reshape(
+                    batch_size * H, tgt_len, src_len).contiguous()
+                stride = tgt_len * src_len
+        drop_p = float(self.attention.dropout) if (self.attention.dropout > 0.0 and self.training) else 0.0
+        drop_u = torch.rand(batch_size * H, tgt_len, src_len, device=dev) if drop_p > 0.0 else None
+        a = self.attention
+        y, attn_w = _MhaFunction.apply(q_bf.to(dt), k_bf, v_bf, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight,
+                                       a.out_proj.bias, add_mask, stride, kpm, drop_u, drop_p, H)
+        attn_output = y if self.batch_first else y.transpose(0, 1)
+        attn_weights = attn_w.to(dt)                                           # [B,T,S], always batch-major
+
+        info: Dict[str, Any] = {}
+        cm = self.curriculum_masking
+        if cm is not None:                                                     # ref :526-541
+            masked_weights, mask_info = cm(attn_weights)
             info.update(mask_info)
             info['attention_weights'] = attn_weights
             if return_info:

@@ -176,6 +176,76 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
                        const void* q, const void* k, const void* v, const float* probs,
                        const void* dout, void* dq, void* dk, void* dv, void* stream);
 
+/* ---- general multi-head attention ----
+ * Everything nn.MultiheadAttention does for MultimodalAttentionPool.forward OUTSIDE the shared-query hot path
+ * (ref aecf/AECFLayer.py:409-418, 480-521; torch functional.py:5836-5852, 6504-6519, 6554-6612): per-sample
+ * queries, tgt_len > 1, key != value, attn_mask, key_padding_mask, attention dropout.  Batch-major tensors.
+ *   Q = query W_q^T + b_q, K = key W_k^T + b_k, V = value W_v^T + b_v            (NT GEMMs)
+ *   per (b,h): p = softmax(Q_h K_h^T / sqrt(hd) + attn_mask, key_padding_mask -> -inf); p' = dropout(p)
+ *   o_h = p' V_h ;  y = o W_o^T + b_o ;  attn_w = mean_h p'   (the weights are returned AFTER dropout, as torch does)
+ * Dropout takes explicit uniforms: keep = (u >= dropout_p), p' = p * keep / (1 - dropout_p)  (torch draws its own
+ * Philox stream inside F.dropout, so the pattern is distribution-, not bit-, compatible).  tgt_len, src_len <= 64. */
+typedef struct aecf_mha_desc {
+    int64_t batch;
+    int32_t tgt_len;      /* T */
+    int32_t src_len;      /* S */
+    int32_t embed_dim;    /* E, multiple of 64, <= 1024 */
+    int32_t num_heads;    /* H, E % H == 0 */
+    int32_t dtype;        /* aecf_dtype of activations and weights */
+    float dropout_p;      /* 0 = no dropout (then dropout_uniforms may be NULL) */
+} aecf_mha_desc;
+
+typedef struct aecf_mha_fwd_args {
+    const void* query;           /* [B,T,E] dtype */
+    const void* key;             /* [B,S,E] dtype */
+    const void* value;           /* [B,S,E] dtype */
+    const void* w_in;            /* [3E,E] */
+    const void* b_in;            /* [3E] or NULL */
+    const void* w_out;           /* [E,E] */
+    const void* b_out;           /* [E] or NULL */
+    const float* attn_mask;      /* additive float32 mask (-inf = blocked) [T,S] or [B*H,T,S], or NULL */
+    int64_t attn_mask_stride;    /* 0 for a shared [T,S] mask, T*S for one per (b*H + h) */
+    const uint8_t* key_padding_mask; /* [B,S] nonzero = ignore, or NULL */
+    const float* dropout_uniforms;   /* [B*H,T,S] float32 U[0,1), or NULL when dropout_p == 0 */
+    void* y;                     /* [B,T,E] dtype */
+    float* attn_w;               /* [B,T,S] head-averaged weights (after dropout) */
+    void* saved_q;               /* [B*T,E] dtype projections, kept for the backward */
+    void* saved_k;               /* [B*S,E] */
+    void* saved_v;               /* [B*S,E] */
+    void* saved_o;               /* [B*T,E] pre-out-projection heads */
+    float* saved_probs;          /* [B,H,T,S] softmax (before dropout) */
+} aecf_mha_fwd_args;
+
+typedef struct aecf_mha_bwd_args {
+    const void* query;
+    const void* key;
+    const void* value;
+    const void* w_in;
+    const void* w_out;
+    const float* dropout_uniforms;
+    const void* dy;              /* [B,T,E] dtype */
+    const float* d_attn_w;       /* [B,T,S] or NULL */
+    const void* saved_q;
+    const void* saved_k;
+    const void* saved_v;
+    const void* saved_o;
+    const float* saved_probs;
+    void* dquery;                /* [B,T,E] dtype */
+    void* dkey;                  /* [B,S,E] dtype */
+    void* dvalue;                /* [B,S,E] dtype */
+    float* dw_in;                /* [3E,E] float32 */
+    float* db_in;                /* [3E]   */
+    float* dw_out;               /* [E,E]  */
+    float* db_out;               /* [E]    */
+    void* workspace;
+    size_t workspace_bytes;
+} aecf_mha_bwd_args;
+
+int aecf_mha_check(const aecf_mha_desc* d);
+size_t aecf_mha_bwd_workspace_bytes(const aecf_mha_desc* d);
+int aecf_mha_forward(const aecf_mha_desc* d, const aecf_mha_fwd_args* a, void* stream);
+int aecf_mha_backward(const aecf_mha_desc* d, const aecf_mha_bwd_args* a, void* stream);
+
 /* ---- missing-modality front-end (ref xrays/train_xrays_example.py:156-177, 202-203) ----
  * One pass over one modality's feature rows feat [rows,dim]: rows with drop[r] != 0 are zeroed (the reference's
  * clone + masked write, :173-176) and present[r] = (||row||_2 > 1e-6) of the row AS WRITTEN (the reference's

@@ -49,7 +49,9 @@ def mha_forward(
     b_out: Optional[Tensor],  # [E]
     num_heads: int,
     key_padding_mask: Optional[Tensor] = None,  # [B,S] bool, True = ignore
-    attn_mask: Optional[Tensor] = None,          # [T,S] bool (True = blocked) or float additive
+    attn_mask: Optional[Tensor] = None,          # [T,S] or [B*H,T,S]; bool (True = blocked) or float additive
+    dropout_u: Optional[Tensor] = None,          # [B,H,T,S] uniforms: keep = (u >= dropout_p)   (torch:6591-6592)
+    dropout_p: float = 0.0,
 ) -> Dict[str, Tensor]:
     """Need-weights branch of multi_head_attention_forward, torch:nn/functional.py:6576-6612.
 
@@ -72,22 +74,28 @@ def mha_forward(
     scores = (qh * scale) @ kh.transpose(-1, -2)        # torch:6589 (F6)  [B,H,T,S]
     neg_inf = float("-inf")
     if attn_mask is not None:                           # torch:6584-6587
+        am = attn_mask.reshape(1, 1, T, S) if attn_mask.dim() == 2 else attn_mask.reshape(B, H, T, S)
         if attn_mask.dtype == torch.bool:
-            scores = scores.masked_fill(attn_mask.reshape(1, 1, T, S), neg_inf)
+            scores = scores.masked_fill(am, neg_inf)
         else:
-            scores = scores + attn_mask.reshape(1, 1, T, S).to(scores.dtype)
+            scores = scores + am.to(scores.dtype)
     if key_padding_mask is not None:                    # torch:6554-6566
         scores = scores.masked_fill(key_padding_mask.reshape(B, 1, 1, S), neg_inf)
     m = scores.max(dim=-1, keepdim=True).values
     e = torch.exp(scores - m)
     p = e / e.sum(dim=-1, keepdim=True)                 # torch:6590 (F7)
-    oh = p @ vh                                         # torch:6594 (F9)  [B,H,T,hd]
+    keep = None
+    pd = p
+    if dropout_p > 0.0:                                 # torch:6591-6592: the weights are dropped out, then used AND returned
+        keep = (dropout_u.reshape(B, H, T, S) >= dropout_p).to(p.dtype) / (1.0 - dropout_p)
+        pd = p * keep
+    oh = pd @ vh                                        # torch:6594 (F9)  [B,H,T,hd]
     o = oh.permute(0, 2, 1, 3).reshape(B, T, E)         # torch:6596-6599 (F10)
     y = o @ w_out.T                                     # torch:6600 (F11)
     if b_out is not None:
         y = y + b_out
-    wbar = p.mean(dim=1)                                # torch:6604-6606 (F12) [B,T,S]
-    return dict(y=y, wbar=wbar, p=p, o=o, qp=qp, kp=kp, vp=vp)
+    wbar = pd.mean(dim=1)                               # torch:6604-6606 (F12) [B,T,S]
+    return dict(y=y, wbar=wbar, p=p, pd=pd, keep=keep, o=o, qp=qp, kp=kp, vp=vp)
 
 
 def mha_backward(
@@ -120,7 +128,10 @@ def mha_backward(
     dp = doh @ vh.transpose(-1, -2)                        # [B,H,T,S]
     if dwbar is not None:
         dp = dp + dwbar.unsqueeze(1) / H                   # mean over heads
-    dvh = p.transpose(-1, -2) @ doh                        # [B,H,S,hd]
+    pd, keep = fwd.get("pd", p), fwd.get("keep")
+    dvh = pd.transpose(-1, -2) @ doh                       # [B,H,S,hd]
+    if keep is not None:
+        dp = dp * keep                                     # back through the dropout
     ds = p * (dp - (p * dp).sum(-1, keepdim=True))         # softmax backward
     dqh = (ds @ kh) * scale
     dkh = ds.transpose(-1, -2) @ (qh * scale)

@@ -396,7 +396,66 @@ def g10_model_step():
     print("g10 model step: loss", float(loss), "params", sum(p.numel() for p in model.parameters()))
 
 
+def g11_general():
+    """nn.MultiheadAttention options outside the shared-query path, from the reference module itself:
+    attn_mask (bool 2-D, float 3-D), key_padding_mask, key != value, tgt_len > 1, per-sample queries, seq-first."""
+    out = {}
+    cases = [
+        # name, E, H, B, T, S, mask kind, kpm, value!=key, batch_first
+        ("bool2d", 64, 2, 6, 3, 4, "bool2d", False, False, True),
+        ("float3d_kpm", 64, 4, 5, 2, 5, "float3d", True, False, True),
+        ("kv_diff", 128, 2, 4, 3, 3, None, True, True, True),
+        ("seqfirst", 64, 2, 4, 2, 3, "bool2d", False, True, False),
+    ]
+    for i, (name, E, H, B, T, S, mk, kpm, vdiff, bfirst) in enumerate(cases):
+        pool = make_pool(E, H, 700 + i, batch_first=bfirst)
+        pool.eval()
+        g = torch.Generator().manual_seed(800 + i)
+        q = (torch.randn(B, T, E, generator=g) * 0.5).requires_grad_(True)
+        k = torch.randn(B, S, E, generator=g).requires_grad_(True)
+        v = (torch.randn(B, S, E, generator=g) if vdiff else None)
+        if v is not None:
+            v.requires_grad_(True)
+        dy = torch.randn(B, T, E, generator=g)
+        dwbar = torch.randn(B, T, S, generator=g)
+        am = None
+        if mk == "bool2d":
+            am = torch.rand(T, S, generator=g) < 0.3
+            am[:, 0] = False
+        elif mk == "float3d":
+            am = torch.randn(B * H, T, S, generator=g)
+        mask = None
+        if kpm:
+            mask = torch.rand(B, S, generator=g) < 0.3
+            mask[:, 0] = False
+        tr = (lambda t_: t_) if bfirst else (lambda t_: t_.transpose(0, 1))
+        y, info = pool(tr(q), tr(k), None if v is None else tr(v), key_padding_mask=mask, attn_mask=am, return_info=True)
+        wbar = info["attention_weights"]                  # always [B,T,S]
+        loss = (tr(y) * dy).sum() + (wbar * dwbar).sum()
+        loss.backward()
+        a = pool.attention
+        d = dict(E=E, H=H, B=B, T=T, S=S, batch_first=int(bfirst), query=npy(q), key=npy(k), dy=npy(dy), dwbar=npy(dwbar),
+                 w_in=npy(a.in_proj_weight), b_in=npy(a.in_proj_bias), w_out=npy(a.out_proj.weight),
+                 b_out=npy(a.out_proj.bias), y=npy(tr(y)), wbar=npy(wbar), dquery=npy(q.grad), dkey=npy(k.grad),
+                 dw_in=npy(a.in_proj_weight.grad), db_in=npy(a.in_proj_bias.grad), dw_out=npy(a.out_proj.weight.grad),
+                 db_out=npy(a.out_proj.bias.grad))
+        if v is not None:
+            d["value"] = npy(v)
+            d["dvalue"] = npy(v.grad)
+        if am is not None:
+            d["attn_mask"] = npy(am)
+        if mask is not None:
+            d["key_padding_mask"] = npy(mask)
+        for kk, vv in d.items():
+            out[f"{name}.{kk}"] = vv
+        print("g11", name, tuple(y.shape), float(y.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "g11_general.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":
+        g11_general()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g10":
         g10_model_step()
         sys.exit(0)

@@ -142,3 +142,26 @@ def test_info_nce_backward_matches_autograd():
     dza, dzb = O.info_nce_backward(za.detach(), zb.detach(), 0.1)
     assert torch.allclose(dza, za.grad, atol=1e-10)
     assert torch.allclose(dzb, zb.grad, atol=1e-10)
+
+
+def test_oracle_general_options_match_reference():
+    """g11: attn_mask (bool 2-D, float 3-D), key_padding_mask, key != value, tgt_len > 1 from the reference module."""
+    from oracle import aecf_oracle as O
+    g = load_npz("g11_general.npz")
+    for name in ("bool2d", "float3d_kpm", "kv_diff", "seqfirst"):
+        c = {k.split(".", 1)[1]: g[k] for k in g if k.startswith(name + ".")}
+        T = lambda k: torch.from_numpy(np.asarray(c[k]))
+        q, key = T("query"), T("key")
+        value = T("value") if "value" in c else key
+        am = T("attn_mask") if "attn_mask" in c else None
+        kpm = T("key_padding_mask") if "key_padding_mask" in c else None
+        H = int(c["H"])
+        f = O.mha_forward(q, key, value, T("w_in"), T("b_in"), T("w_out"), T("b_out"), H, kpm, am)
+        b = O.mha_backward(q, key, value, T("w_in"), T("b_in"), T("w_out"), H, f, T("dy"), T("dwbar"))
+        assert rel_err(f["y"], c["y"]) < 2e-6 and rel_err(f["wbar"], c["wbar"]) < 2e-6, name
+        dk = b["dkey"] + (b["dvalue"] if "value" not in c else 0)
+        assert rel_err(b["dquery"], c["dquery"]) < 5e-6 and rel_err(dk, c["dkey"]) < 5e-6, name
+        if "value" in c:
+            assert rel_err(b["dvalue"], c["dvalue"]) < 5e-6, name
+        for k_ in ("dw_in", "db_in", "dw_out", "db_out"):
+            assert rel_err(b[k_], c[k_]) < 5e-6, (name, k_)

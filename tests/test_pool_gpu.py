@@ -335,17 +335,17 @@ def test_fused_mask_equals_oracle_on_kernel_weights():
 def test_unsupported_configurations_fail_loudly():
     import aecf_amd
     dev = _dev()
-    pool = aecf_amd.MultimodalAttentionPool(64, num_heads=2).to(dev)
     x = torch.randn(4, 3, 64, device=dev)
-    with pytest.raises(NotImplementedError):
-        pool(torch.randn(4, 1, 64, device=dev), x)                    # per-sample queries
-    with pytest.raises(NotImplementedError):
-        pool(torch.randn(1, 1, 64, device=dev).expand(4, -1, -1), x, x.clone())   # value is not key
-    with pytest.raises(NotImplementedError):
-        pool(torch.randn(1, 1, 64, device=dev).expand(4, -1, -1), x, attn_mask=torch.zeros(1, 3, device=dev))
-    pool8 = aecf_amd.MultimodalAttentionPool(64, num_heads=8).to(dev)           # head_dim 8
+    pool8 = aecf_amd.MultimodalAttentionPool(64, num_heads=8).to(dev)           # head_dim 8 on the shared-query path
     with pytest.raises(RuntimeError, match="not supported"):
         pool8(torch.randn(1, 1, 64, device=dev).expand(4, -1, -1), x)
+    pool = aecf_amd.MultimodalAttentionPool(64, num_heads=2).to(dev)
+    with pytest.raises(RuntimeError, match="not supported"):                    # src_len beyond the general kernels
+        pool(torch.randn(4, 2, 64, device=dev), torch.randn(4, 65, 64, device=dev))
+    with pytest.raises(RuntimeError, match="2D attn_mask"):
+        pool(torch.randn(4, 2, 64, device=dev), x, attn_mask=torch.zeros(3, 3, device=dev))
+    with pytest.raises(NotImplementedError):
+        pool(torch.randn(4, 1, 64, device=dev).double(), x.double())            # float64 is not built
 
 
 def test_g10_model_step_matches_reference():
