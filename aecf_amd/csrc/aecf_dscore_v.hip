@@ -2,8 +2,9 @@
 //     da[b,h,m] = do_h[b] . V_h[b,m]        V[b,m,:] = W_v x[b,m,:] + b_v   (written by the forward V projection)
 //     dp = da + dwbar[b,m]/H ;  ds[b,h,:] = a * (dp - sum_m a dp)            (softmax backward)
 // Memory-bound: one wave per sample reads do[b,:] and the M rows V[b,m,:] once with 16-byte loads; a lane's chunk
-// (8 bf16 / 4 f32 consecutive columns) lies inside one head, heads span LPH = head_dim*BYTES/16 consecutive lanes
-// (a power of two), so the per-head dot is an xor-shuffle tree -- deterministic, no LDS, no atomics.
+// (8 bf16 / 4 f32 consecutive columns) lies inside one head, a head spans LPH = head_dim*BYTES/16 consecutive lanes and
+// each wave pass covers 64/LPH whole heads, so the per-head dot is an xor-shuffle tree (LPH a power of two) or a
+// fixed-order gather over the head's lanes (any LPH, e.g. head_dim 96) -- deterministic, no LDS, no atomics.
 #include "aecf_kernels.h"
 
 namespace aecf {
@@ -17,7 +18,9 @@ __global__ __launch_bounds__(256) void dscore_v_kernel(BwdGArgs p, const typenam
     if (b >= p.B) return;
     const int lane = lane_id();
     const int E = p.E, H = p.H;
-    const int nchunk = E / CH;                        // chunks per row; chunk c = lane + 64*i
+    const int hpp = 64 / lph;                         // whole heads per wave pass
+    const int hl = lane / lph, within = lane - hl * lph;
+    const bool pow2 = (lph & (lph - 1)) == 0;
     const elem* dorow = reinterpret_cast<const elem*>(p.dobuf) + b * (int64_t)E;
     const elem* vrow = V + b * M_ * (int64_t)E;
     const float invH = 1.0f / (float)H;
@@ -35,9 +38,10 @@ __global__ __launch_bounds__(256) void dscore_v_kernel(BwdGArgs p, const typenam
         for (int m = 0; m < M_; ++m) dwb[m] += live ? -(logf(wv[m]) + 1.0f) * de : 0.f;
     }
 
-    for (int c0 = 0; c0 < nchunk; c0 += 64) {
-        const int c = c0 + lane;
-        const bool on = c < nchunk;
+    for (int h0 = 0; h0 < H; h0 += hpp) {
+        const int h = h0 + hl;
+        const bool on = hl < hpp && h < H;
+        const int c = h * lph + within;               // this lane's 16-byte chunk of the row
         float part[M_];
 #pragma unroll
         for (int m = 0; m < M_; ++m) part[m] = 0.f;
@@ -54,13 +58,26 @@ __global__ __launch_bounds__(256) void dscore_v_kernel(BwdGArgs p, const typenam
                 part[m] = a;
             }
         }
-        // sum over the lph lanes of each head (lph is a power of two <= 64, heads are lane-aligned)
-        for (int off = 1; off < lph; off <<= 1) {
+        // sum over the lph lanes of each head (heads are lane-aligned: lanes hl*lph .. hl*lph + lph - 1)
+        if (pow2) {
+            for (int off = 1; off < lph; off <<= 1) {
 #pragma unroll
-            for (int m = 0; m < M_; ++m) part[m] += __shfl_xor(part[m], off, 64);
+                for (int m = 0; m < M_; ++m) part[m] += __shfl_xor(part[m], off, 64);
+            }
+        } else {
+            float tot[M_];
+#pragma unroll
+            for (int m = 0; m < M_; ++m) tot[m] = 0.f;
+            const int base = hl * lph < 64 ? hl * lph : 0;
+            for (int i = 0; i < lph; ++i) {
+                const int srcl = (base + i) & 63;
+#pragma unroll
+                for (int m = 0; m < M_; ++m) tot[m] += __shfl(part[m], srcl, 64);
+            }
+#pragma unroll
+            for (int m = 0; m < M_; ++m) part[m] = tot[m];
         }
-        if (on && (lane & (lph - 1)) == 0) {
-            const int h = c / lph;
+        if (on && within == 0) {
             float pm[M_], dp[M_], dot = 0.f;
 #pragma unroll
             for (int m = 0; m < M_; ++m) {
@@ -77,7 +94,7 @@ __global__ __launch_bounds__(256) void dscore_v_kernel(BwdGArgs p, const typenam
 bool launch_dscore_v(int dtype, const BwdGArgs& a, const void* saved_v, hipStream_t s) {
     const int bytes = dtype == 0 ? 2 : 4;
     const int lph = a.hd * bytes / 16;               // lanes per head
-    if (lph < 1 || lph > 64 || (lph & (lph - 1)) != 0 || (a.hd * bytes) % 16 != 0) return false;
+    if (lph < 1 || lph > 64 || (a.hd * bytes) % 16 != 0) return false;
     dim3 grid((unsigned)((a.B + 3) / 4)), block(256);
     AECF_DISPATCH_M(a.M, {
         if (dtype == 0) dscore_v_kernel<BF16, M_><<<grid, block, 0, s>>>(a, (const unsigned short*)saved_v, lph);
