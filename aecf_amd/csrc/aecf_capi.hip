@@ -49,14 +49,13 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     S = (int)((B + rps - 1) / rps);
     w.splits = S;
     w.rows_per_split = rps;
-    {   // u = ds^T x: [16, E] per split -> ~1024 blocks
-        const int kt = (int)((E + 127) / 128);
-        int Su = (1024 + kt - 1) / kt;
+    {   // u = ds^T x: [16, E] per batch split, ~512 blocks of 8 waves (2 per CU)
+        int Su = 512;
         const int64_t max_su = (int64_t)((B + 63) / 64);
         if (Su > max_su) Su = (int)max_su;
         if (Su < 1) Su = 1;
         int64_t urps = (int64_t)((B + Su - 1) / Su);
-        urps = (urps + 63) / 64 * 64;
+        urps = (urps + 15) / 16 * 16;
         w.u_splits = (int)((B + urps - 1) / urps);
         w.u_rows_per_split = urps;
     }

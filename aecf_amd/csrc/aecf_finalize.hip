@@ -23,9 +23,19 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs r) {
         if (q < nq) {
             const bool on = 4 * q < r.n[s];
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (on)
-                for (int k = g; k < r.splits[s]; k += 4)
-                    a += *reinterpret_cast<const f32x4*>(r.src[s] + (int64_t)k * r.n[s] + 4 * q);
+            if (on) {
+                const float* base = r.src[s] + 4 * q;
+                const int64_t n = r.n[s];
+                int k = g;
+                for (; k + 28 < r.splits[s]; k += 32) {           // 8 independent loads in flight, summed in order
+                    f32x4 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(k + 4 * j) * n);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += v[j];
+                }
+                for (; k < r.splits[s]; k += 4) a += *reinterpret_cast<const f32x4*>(base + (int64_t)k * n);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 a[c] += __shfl_xor(a[c], 16, 64);

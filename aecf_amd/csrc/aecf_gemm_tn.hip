@@ -351,11 +351,101 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_u_kernel(GemmTnArgs p) {
     }
 }
 
+// u = ds^T x as a streaming kernel on the vector ALU (float32 exact): x is read ONCE, 16 bytes per lane; a wave owns a
+// 64-lane slice of the row (512 bf16 / 256 f32 columns) and keeps u[8 heads][its columns] in registers; the softmax-
+// gradient scalars ds[b, h, m] are wave-uniform (scalar loads).  8 waves per block walk the block's batch split, then
+// fold their partial sums through LDS in a fixed order.  grid (column slices, head groups of 8, batch splits).
+template <typename T, int M_>
+__global__ __launch_bounds__(512, 2) void u_stream_kernel(GemmTnArgs p) {
+    using X = Tr<T>;
+    constexpr int CH = X::EPL;                         // columns per lane
+    constexpr int HG = 8;                              // heads per block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);       // [8 waves][4 heads][64 * CH]
+    const int E = p.E, H = p.H;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const int col = (blockIdx.x * 64 + lane) * CH;
+    const bool c_on = col < E;
+    const int h0 = blockIdx.y * HG;
+    const int nh = (H - h0) < HG ? (H - h0) : HG;
+    const int split = blockIdx.z;
+    const int64_t rbeg = (int64_t)split * p.u_rows_per_split;
+    const int64_t rend = (rbeg + p.u_rows_per_split) < p.B ? (rbeg + p.u_rows_per_split) : p.B;
+    const typename X::elem* x = reinterpret_cast<const typename X::elem*>(p.rhs);
+
+    float acc[HG][CH];
+#pragma unroll
+    for (int h = 0; h < HG; ++h)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[h][c] = 0.f;
+
+    for (int64_t b0 = rbeg + w; b0 < rend; b0 += 16) {             // two samples (b0, b0 + 8) per iteration
+        typename X::frag xr[2][M_];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int64_t b = b0 + 8 * s2;
+#pragma unroll
+            for (int m = 0; m < M_; ++m)
+                xr[s2][m] = (c_on && b < rend) ? X::load(x + (b * M_ + m) * (int64_t)E + col) : X::zero();
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int64_t b = b0 + 8 * s2;
+            if (b < rend) {                                         // wave-uniform
+                const float* dsp = p.dsbuf + (b * H + h0) * M_;
+#pragma unroll
+                for (int m = 0; m < M_; ++m) {
+                    float xv[CH];
+                    X::unpack(xr[s2][m], xv);
+#pragma unroll
+                    for (int h = 0; h < HG; ++h) {
+                        if (h < nh) {
+                            const float d = dsp[h * M_ + m];
+#pragma unroll
+                            for (int c = 0; c < CH; ++c) acc[h][c] = fmaf(d, xv[c], acc[h][c]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // fold the 8 waves' partials in wave order, 4 heads per pass
+    float* u = p.u + (int64_t)split * HPAD * E;
+    constexpr int SL = 64 * CH;                         // columns of the slice
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) red[(w * 4 + hh) * SL + lane * CH + c] = acc[4 * pass + hh][c];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * SL; i += 512) {
+            const int hh = i / SL, cc = i - hh * SL;
+            float a = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) a += red[(ww * 4 + hh) * SL + cc];
+            const int h = h0 + 4 * pass + hh, k = blockIdx.x * SL + cc;
+            if (h < HPAD && k < E) u[(int64_t)h * E + k] = h < H ? a : 0.f;
+        }
+    }
+    // rows H..HPAD-1 that no head group covers stay zero for the consumers
+    if (blockIdx.y == 0) {
+        const int covered = ((H + HG - 1) / HG) * HG;
+        for (int i = threadIdx.x; i < (HPAD - covered) * SL; i += 512) {
+            const int h = covered + i / SL, k = blockIdx.x * SL + i % SL;
+            if (h < HPAD && k < E) u[(int64_t)h * E + k] = 0.f;
+        }
+    }
+}
+
 template <typename T, int M_>
 static void launch_u(const GemmTnArgs& a, hipStream_t s) {
-    const size_t smem = (size_t)M_ * 128 * TILE_ROW_BYTES;
-    dim3 grid((a.E + 127) / 128, 1, a.u_splits), block(256);
-    auto kern = gemm_tn_u_kernel<T, M_>;
+    constexpr int SL = 64 * Tr<T>::EPL;
+    const size_t smem = (size_t)8 * 4 * SL * sizeof(float);
+    dim3 grid((a.E + SL - 1) / SL, (a.H + 7) / 8, a.u_splits), block(512);
+    auto kern = u_stream_kernel<T, M_>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     kern<<<grid, block, smem, s>>>(a);
