@@ -223,28 +223,32 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dx on the same engine:   dx[b,m,k] = sum_j (probs[b,h(j),m] do[b,j]) W_v[j,k]  +  sum_h ds[b,h,m] A[h,k]
-// Rows (b,m) of the MFMA B operand are M scaled copies of the do row (the head-wise softmax weights applied on the INPUT
-// side: B*E*M multiplies instead of the B*H*E*M fused multiply-adds of weighting g_h = W_v,h^T do_h on the output
-// side), the resident A operand is W_v^T, and the key-side term rides along as KX extra K-steps: entries
-// [ds_hi(h) | ds_lo(h) | ds_hi(h)] against [A_hi[h] | A_hi[h] | A_lo[h]] (bf16 hi/lo splits, ~16 mantissa bits).
-// Per step (16 samples): DMA of the raw do rows (double buffered), a cooperative scaling pass into the swizzled
-// operand tile, two barriers, M*(KT+KX) operand reads / 2x as many MFMAs per wave, M 16-byte stores per lane.
-template <int KT, int M_, int KX>
-__global__ __launch_bounds__(512, 2) void dx_ws_kernel(BwdGArgs p, int rows_per_block, int nchunk) {
+// dx on the same engine: the softmax weights applied on the OUTPUT side, per head, in the accumulator layout.
+// (A first form scaled M copies of each do row on the input side -- a cooperative pass into a second LDS tile, two
+// barriers per step, 3x the operand reads: 122 us against 87 us for this one at C2.)
+//     P_h[b, k] = sum_{j in head h} do[b, j] W_v[j, k]            (MFMA over the head's HK = hd/32 K-steps)
+//     dx[b, m, k] = sum_h probs[b, h, m] P_h[b, k]  +  sum_h ds[b, h, m] A[h, k]
+// In the transposed product a lane holds 8 output columns of ONE sample, so probs[b, h, m] is a per-lane scalar and
+// the weighting is M*8 FMAs per head on registers: no scaled operand tile, no scaling pass, no second barrier, and the
+// LDS operand traffic of one raw do row per sample instead of M scaled rows.  The key-side term is KX extra MFMA
+// K-steps whose B operand ([ds_hi | ds_lo | ds_hi] entries of the lane's sample) is built in registers.
+template <int KT, int HK, int M_>
+__global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
-    constexpr int K = 32 * KT, ROWB = 2 * K, CPR = 4 * KT;
-    constexpr int SROWS = 16 * M_;
-    constexpr int RAW = 16 * ROWB, TILE = SROWS * ROWB;
-    constexpr int XROWB = 64 * KX;                                // bytes per row of the extra-K tile
+    constexpr int K = 32 * KT, ROWB = 2 * K;
+    constexpr int H_ = KT / HK;                                    // heads
+    constexpr int KX = (3 * H_ + 31) / 32;
+    constexpr int RAW = 16 * ROWB;
+    constexpr int HM = H_ * M_, NST = 16 * HM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* raw = smem;                                             // [2][16][K] do rows as they are in memory
-    char* scaled = smem + 2 * RAW;                                // [16*M][K]  rows b*M+m, chunk ^ b
-    char* xtra = scaled + TILE;                                   // [16*M][32*KX] ds hi/lo entries
-    float* stage = reinterpret_cast<float*>(xtra + SROWS * XROWB);   // [2][16*H*M]: probs | ds of the current step
+    constexpr int XROWB = 64 * KX;                                // bytes per row of the key-side operand tile
+    constexpr int XT = 16 * M_ * XROWB;
+    char* raw = smem;                                             // [2][16][K] do rows, chunk ^ row
+    float* stage = reinterpret_cast<float*>(smem + 2 * RAW);      // [2][16][H][M] softmax weights, double buffered
+    char* xtra = smem + 2 * RAW + 2 * NST * 4;                    // [2][16*M][32*KX] bf16 [ds_hi | ds_lo | ds_hi] rows
 
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
-    const int E = p.E, H = p.H, HM = p.H * M_, nst = 16 * HM;
+    const int E = p.E;
     unsigned int chunk_u, group_u;
     if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(E / 256), chunk_u, group_u)) return;
     const int ncol0 = (int)group_u * 256 + 32 * w;
@@ -252,7 +256,6 @@ __global__ __launch_bounds__(512, 2) void dx_ws_kernel(BwdGArgs p, int rows_per_
     const int64_t o_end = (o_beg + rows_per_block) < p.B ? (o_beg + rows_per_block) : p.B;
     if (o_beg >= o_end) return;
 
-    // ---- resident operand: W_v^T rows (output columns) n(c,i) = ncol0 + 8 (i >> 2) + 4 c + (i & 3), plus the A entries
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.wvt);
     u32x4 wreg[KT + KX][2];
 #pragma unroll
@@ -267,156 +270,157 @@ __global__ __launch_bounds__(512, 2) void dx_ws_kernel(BwdGArgs p, int rows_per_
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int e = 32 * kx + 8 * lg + j;               // entry: [0,H) A_hi, [H,2H) A_hi, [2H,3H) A_lo
-                const int h = e < H ? e : (e < 2 * H ? e - H : e - 2 * H);
+                const int h = e < H_ ? e : (e < 2 * H_ ? e - H_ : e - 2 * H_);
                 float a = 0.f;
-                if (e < 3 * H) {
+                if (e < 3 * H_) {
                     a = p.a_f32[(int64_t)h * E + n];
                     const float hi = X::to_f32(X::from_f32(a));
-                    a = e < 2 * H ? hi : a - hi;
+                    a = e < 2 * H_ ? hi : a - hi;
                 }
                 v[j] = a;
             }
             wreg[KT + kx][c] = X::pack(v);
         }
     }
-
-    // operand read addresses (see gemm_ws_kernel): row r16*M + m, chunk (4 ks + lg) ^ r16
     int xaddr[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) xaddr[v] = r16 * M_ * ROWB + ((((4 * v) + lg) ^ r16) << 4);
-    const int xxaddr = r16 * M_ * XROWB + 16 * lg;
+    for (int v = 0; v < 4; ++v) xaddr[v] = r16 * ROWB + ((((4 * v) + lg) ^ r16) << 4);
 
     const char* dsrc = reinterpret_cast<const char*>(p.dobuf);
     auto issue = [&](int64_t o0, int buf) {
         const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
-        ws_dma_rows<KT, 16, 1 << 30>(dsrc + o0 * (int64_t)ROWB, (unsigned)ROWB, ov, raw + buf * RAW);   // key 0: linear rows
+        ws_dma_rows<KT, 16, 1>(dsrc + o0 * (int64_t)ROWB, (unsigned)ROWB, ov, raw + buf * RAW);
     };
-    // probabilities and score gradients of a step: [16][H][M] floats each, fetched one step ahead by inline asm loads
-    // (see gemm_ws_kernel) and parked in LDS after the end-of-step wait
-    float stg[2][2];
+    constexpr int NSI = (NST + 511) / 512;
+    float stg[NSI][2];
     auto load_stage = [&](int64_t o0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NSI; ++i) {
             const int idx = threadIdx.x + 512 * i;
             const int bb = idx / HM, rem = idx - bb * HM;
             const int64_t b = (o0 + bb) < o_end ? (o0 + bb) : (o_end - 1);
             const float* pp = p.probs + b * HM + rem;
             const float* dp = p.dsbuf + b * HM + rem;
-            if (idx < nst) {
+            if (idx < NST) {
                 asm volatile("global_load_dword %0, %1, off" : "=v"(stg[i][0]) : "v"(pp) : "memory");
                 asm volatile("global_load_dword %0, %1, off" : "=v"(stg[i][1]) : "v"(dp) : "memory");
             }
         }
     };
-    auto park_stage = [&]() {
+    auto park_stage = [&](int buf) {                               // into the buffer the NEXT step reads
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NSI; ++i) {
             const int idx = threadIdx.x + 512 * i;
             asm volatile("" : "+v"(stg[i][0]), "+v"(stg[i][1]));
-            if (idx < nst) {
-                stage[idx] = stg[i][0];
-                stage[nst + idx] = stg[i][1];
+            if (idx < NST) {
+                stage[buf * NST + idx] = stg[i][0];
+                const int bb = idx / HM, rem = idx - bb * HM, h = rem / M_, m = rem - h * M_;
+                const float d = stg[i][1];
+                const unsigned short hi = X::from_f32(d);
+                const unsigned short lo = X::from_f32(d - X::to_f32(hi));
+                unsigned short* xr = reinterpret_cast<unsigned short*>(xtra + buf * XT + (bb * M_ + m) * XROWB);
+                xr[h] = hi;
+                xr[H_ + h] = lo;
+                xr[2 * H_ + h] = hi;
             }
         }
     };
 
-    for (int i = threadIdx.x; i < SROWS * XROWB / 4; i += 512) reinterpret_cast<unsigned int*>(xtra)[i] = 0u;
+    for (int i = threadIdx.x; i < 2 * XT / 4; i += 512) reinterpret_cast<unsigned int*>(xtra)[i] = 0u;   // padding entries
     issue(o_beg, 0);
     load_stage(o_beg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    park_stage();
+    __syncthreads();
+    park_stage(0);
     int cur = 0;
     for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // raw rows + stage visible; operand tile free
+        __builtin_amdgcn_s_barrier();                              // do rows + stage of this step visible
         if (o0 + 16 < o_end) {
             issue(o0 + 16, cur ^ 1);
             load_stage(o0 + 16);
         }
-        // ---- scaling pass: operand row (b, m) = probs[b, head, m] * do[b, :]
-        {
-            const char* rt = raw + cur * RAW;
+        const char* tb = raw + cur * RAW;
+        const float* sp = stage + cur * NST + r16 * HM;            // this lane's sample: probs[h][m]
+        const char* xq = xtra + cur * XT + r16 * M_ * XROWB + 16 * lg;
+        f32x4 acc[M_][2];
 #pragma unroll
-            for (int i = 0; i < (16 * CPR + 511) / 512; ++i) {
-                const int c = threadIdx.x + 512 * i;
-                if ((16 * CPR) % 512 == 0 || c < 16 * CPR) {
-                    const int b = c / CPR, pch = c - b * CPR;
-                    float v[8];
-                    X::unpack(*reinterpret_cast<const u32x4*>(rt + b * ROWB + pch * 16), v);
-                    const float* pr = stage + (b * H + (8 * pch) / p.hd) * M_;
-#pragma unroll
-                    for (int m = 0; m < M_; ++m) {
-                        const float pm = pr[m];
-                        float sv[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) sv[j] = pm * v[j];
-                        *reinterpret_cast<u32x4*>(scaled + (b * M_ + m) * ROWB + ((pch ^ b) << 4)) = X::pack(sv);
-                    }
-                }
-            }
-            for (int t = threadIdx.x; t < 16 * HM; t += 512) {     // (b, h, m): hi/lo entries of ds
-                const int b = t / HM, rem = t - b * HM, h = rem / M_, m = rem - h * M_;
-                const float d = stage[nst + t];
-                const unsigned short hi = X::from_f32(d);
-                const unsigned short lo = X::from_f32(d - X::to_f32(hi));
-                unsigned short* xr = reinterpret_cast<unsigned short*>(xtra + (b * M_ + m) * XROWB);
-                xr[h] = hi;
-                xr[H + h] = lo;
-                xr[2 * H + h] = hi;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // operand tile visible
+        for (int m = 0; m < M_; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // ---- products, modality-major (one accumulator pair live), reads PF items ahead (see gemm_ws_kernel)
-        constexpr int KK = KT + KX, NIT = M_ * KK, PF = 3;
-        auto rd = [&](int i) -> u32x4 {
-            const int m = i / KK, ks = i % KK;
-            if (ks < KT) return *reinterpret_cast<const u32x4*>(scaled + xaddr[ks & 3] + m * ROWB + (ks >> 2) * 256);
-            return *reinterpret_cast<const u32x4*>(xtra + xxaddr + m * XROWB + (ks - KT) * 64);
+        // key-side term first: B operand of modality m = entries [ds_hi | ds_lo | ds_hi] of this lane's sample
+#pragma unroll
+        for (int m = 0; m < M_; ++m)
+#pragma unroll
+            for (int kx = 0; kx < KX; ++kx) {
+                const u32x4 df = *reinterpret_cast<const u32x4*>(xq + m * XROWB + 64 * kx);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[m][c] = X::mma(wreg[KT + kx][c], df, acc[m][c]);
+            }
+
+        // value-side term, head by head; operand reads run PF K-steps ahead
+        constexpr int PF = 3;
+        auto rd = [&](int ks) -> u32x4 {
+            return *reinterpret_cast<const u32x4*>(tb + xaddr[ks & 3] + (ks >> 2) * 256);
         };
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        u32x4 vpk[M_];
         u32x4 xf[PF + 1];
 #pragma unroll
         for (int i = 0; i < PF; ++i) xf[i] = rd(i);
-        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+        // software pipeline over heads: the MFMAs of head h+1 are issued in the same scheduling region as the FMAs that
+        // apply head h (the matrix pipe and the vector ALU overlap); a scheduling fence per head keeps only two P sets live
+        f32x4 Pc[2], Pn[2];
+        auto head_mma = [&](int h, f32x4* P) {
+            P[0] = P[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
-            const int ks = i % KK;
+            for (int kl = 0; kl < HK; ++kl) {
+                const int ks = h * HK + kl;
+                if (ks + PF < KT) xf[(ks + PF) % (PF + 1)] = rd(ks + PF);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[c]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            if (ks == KK - 1) {
+                for (int c = 0; c < 2; ++c) P[c] = X::mma(wreg[ks][c], xf[ks % (PF + 1)], P[c]);
+            }
+        };
+        head_mma(0, Pc);
+#pragma unroll
+        for (int h = 0; h < H_; ++h) {
+            if (h + 1 < H_) head_mma(h + 1, Pn);
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                const float a = sp[h * M_ + m];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m][c][r] = fmaf(a, Pc[c][r], acc[m][c][r]);
+            }
+            // keep the weighting of head h HERE (instruction sinking would otherwise move all H*M*8 FMAs behind the last
+            // MFMA and keep every head's P live)
+#pragma unroll
+            for (int m = 0; m < M_; ++m) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]));
+            __builtin_amdgcn_sched_barrier(0);
+            Pc[0] = Pn[0];
+            Pc[1] = Pn[1];
+        }
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next do rows + stage values landed
+        if (o0 + 16 < o_end) park_stage(cur ^ 1);                  // the other buffer: nobody reads it during this step
+        const int64_t b = o0 + r16;
+        if (b < o_end) {
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
                 float v[8];
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[c][r];
-                vpk[i / KK] = X::pack(v);
-                acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[m][c][r];
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.dx) + (b * M_ + m) * E + ncol0 + 8 * lg) = X::pack(v);
             }
-        }
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next raw rows + stage values landed
-        if (o0 + 16 < o_end) park_stage();
-        const int64_t b = o0 + r16;
-        if (b < o_end) {
-#pragma unroll
-            for (int m = 0; m < M_; ++m)
-                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.dx) + (b * M_ + m) * E + ncol0 + 8 * lg) = vpk[m];
         }
     }
 }
 
-template <int KT, int M_, int KX>
-void launch_dx(const BwdGArgs& a, hipStream_t s) {
+template <int KT, int HK, int M_>
+void launch_dx2(const BwdGArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
-    const size_t smem = (size_t)2 * 16 * 2 * K + (size_t)16 * M_ * 2 * K + (size_t)16 * M_ * 64 * KX +
-                        (size_t)2 * 16 * a.H * M_ * sizeof(float);
+    constexpr int KX = (3 * (KT / HK) + 31) / 32;
+    const size_t smem = (size_t)2 * 16 * 2 * K + (size_t)2 * 16 * (KT / HK) * M_ * sizeof(float) + (size_t)2 * 16 * M_ * 64 * KX;
     const int groups = a.E / 256;
     int64_t chunks = 256 / groups;
     if (chunks < 1) chunks = 1;
@@ -424,29 +428,28 @@ void launch_dx(const BwdGArgs& a, hipStream_t s) {
     rpb = (rpb + 15) / 16 * 16;
     const int64_t nchunk = (a.B + rpb - 1) / rpb;
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
-    auto kern = dx_ws_kernel<KT, M_, KX>;
-    if (smem > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    kern<<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
+    dx_ws2_kernel<KT, HK, M_><<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
 }
 
-template <int M_, int KX>
-void launch_dx_kt(const BwdGArgs& a, hipStream_t s) {
-    switch (a.E / 32) {
-        case 4: launch_dx<4, M_, KX>(a, s); break;
-        case 8: launch_dx<8, M_, KX>(a, s); break;
-        case 12: launch_dx<12, M_, KX>(a, s); break;
-        default: launch_dx<16, M_, KX>(a, s); break;
+template <int KT, int HK>
+void launch_dx2_m(const BwdGArgs& a, hipStream_t s) {
+    switch (a.M) {
+        case 1: launch_dx2<KT, HK, 1>(a, s); break;
+        case 2: launch_dx2<KT, HK, 2>(a, s); break;
+        case 3: launch_dx2<KT, HK, 3>(a, s); break;
+        default: launch_dx2<KT, HK, 4>(a, s); break;
     }
 }
 
-template <int KX>
-void launch_dx_m(const BwdGArgs& a, hipStream_t s) {
-    switch (a.M) {
-        case 1: launch_dx_kt<1, KX>(a, s); break;
-        case 2: launch_dx_kt<2, KX>(a, s); break;
-        case 3: launch_dx_kt<3, KX>(a, s); break;
-        default: launch_dx_kt<4, KX>(a, s); break;
+template <int KT>
+bool launch_dx2_hk(const BwdGArgs& a, hipStream_t s) {
+    switch (a.hd / 32) {
+        case 1: launch_dx2_m<KT, 1>(a, s); return true;
+        case 2: launch_dx2_m<KT, 2>(a, s); return true;
+        case 4: launch_dx2_m<KT, 4>(a, s); return true;
+        case 8: if (KT >= 8) { launch_dx2_m<KT, (KT >= 8 ? 8 : 1)>(a, s); return true; } return false;
+        case 16: if (KT >= 16) { launch_dx2_m<KT, (KT >= 16 ? 16 : 1)>(a, s); return true; } return false;
+        default: return false;
     }
 }
 
@@ -507,10 +510,11 @@ void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s) {
 bool launch_dx_ws(const BwdGArgs& a, hipStream_t s) {
     static const int no_ws = getenv("AECF_NO_WS") ? atoi(getenv("AECF_NO_WS")) : 0;
     if (no_ws) return false;
-    if (a.E % 128 != 0 || a.E < 256 || a.E > 512 || a.E % 256 != 0) return false;
-    if (a.M < 1 || a.M > 4 || a.hd % 8 != 0 || 16 * a.H * a.M > 1024) return false;
-    if (3 * a.H <= 32) launch_dx_m<1>(a, s); else launch_dx_m<2>(a, s);
-    return true;
+    if (a.E != 256 && a.E != 512) return false;
+    if (a.M < 1 || a.M > 4) return false;
+    if (a.hd % 32 != 0 || a.E != a.H * a.hd) return false;
+    if (a.E == 256) return launch_dx2_hk<8>(a, s);
+    return launch_dx2_hk<16>(a, s);
 }
 
 }  // namespace aecf
