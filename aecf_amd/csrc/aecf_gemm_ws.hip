@@ -69,6 +69,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     const int64_t o_end = (o_beg + rows_per_block) < o_all ? (o_beg + rows_per_block) : o_all;
     if (o_beg >= o_end) return;
 
+    const char* asrc = reinterpret_cast<const char*>(p.a);
+    // A rows: PLAIN row r of a [R, lda] matrix; VPROJ row (b, m) of x viewed as [B*M, K] (lda = M*K)
+    const unsigned int row_pitch = (MODE == WS_PLAIN ? (unsigned)p.lda : (unsigned)K) * 2u;
+    const int a_rows_per_o = MODE == WS_PLAIN ? 1 : M_;
+
+    auto issue = [&](int64_t o0, int buf) {                        // DMA of the step that starts at output row o0
+        const int ov = (int)((o_end - o0) < OROWS ? (o_end - o0) : OROWS);
+        ws_dma_rows<KT, SROWS, (MODE == WS_PLAIN ? 1 : M_)>(asrc + o0 * a_rows_per_o * (int64_t)row_pitch, row_pitch,
+                                                            ov * a_rows_per_o, smem + buf * TILE);
+    };
+
+    issue(o_beg, 0);                                              // the first tile flies while the weights load
+
     // ---- resident weights: MFMA A operand, row i = 4 lg' + r of tile c  <->  column ncol0 + 8 (i >> 2) + 4 c + (i & 3)
     //      (so that accumulator lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + 0..3 of row/sample r16)
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w);
@@ -94,17 +107,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     for (int v = 0; v < 4; ++v)
         xaddr[v] = (MODE == WS_PLAIN ? r16 : r16 * M_) * ROWB + ((((4 * v) + lg) ^ r16) << 4);
 
-    const char* asrc = reinterpret_cast<const char*>(p.a);
-    // A rows: PLAIN row r of a [R, lda] matrix; VPROJ row (b, m) of x viewed as [B*M, K] (lda = M*K)
-    const unsigned int row_pitch = (MODE == WS_PLAIN ? (unsigned)p.lda : (unsigned)K) * 2u;
-    const int a_rows_per_o = MODE == WS_PLAIN ? 1 : M_;
-
-    auto issue = [&](int64_t o0, int buf) {                        // DMA of the step that starts at output row o0
-        const int ov = (int)((o_end - o0) < OROWS ? (o_end - o0) : OROWS);
-        ws_dma_rows<KT, SROWS, (MODE == WS_PLAIN ? 1 : M_)>(asrc + o0 * a_rows_per_o * (int64_t)row_pitch, row_pitch,
-                                                            ov * a_rows_per_o, smem + buf * TILE);
-    };
-
     // Synchronisation: the DMA of step s+1 is issued right after the barrier of step s and retired by the
     // s_waitcnt vmcnt(0) that FOLLOWS the MFMAs of step s (a whole step of compute later: it also retires the
     // previous step's stores, so the count is exact); this step's stores are issued after that wait and fly
@@ -122,7 +124,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
                 asm volatile("global_load_dword %0, %1, off" : "=v"(dst[m]) : "v"(pp + m) : "memory");
         }
     };
-    issue(o_beg, 0);
     load_probs(o_beg, pm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -256,6 +257,13 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     const int64_t o_end = (o_beg + rows_per_block) < p.B ? (o_beg + rows_per_block) : p.B;
     if (o_beg >= o_end) return;
 
+    const char* dsrc = reinterpret_cast<const char*>(p.dobuf);
+    auto issue = [&](int64_t o0, int buf) {
+        const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
+        ws_dma_rows<KT, 16, 1>(dsrc + o0 * (int64_t)ROWB, (unsigned)ROWB, ov, raw + buf * RAW);
+    };
+    issue(o_beg, 0);                                              // the first rows fly while the weights load
+
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.wvt);
     u32x4 wreg[KT + KX][2];
 #pragma unroll
@@ -286,11 +294,6 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
 #pragma unroll
     for (int v = 0; v < 4; ++v) xaddr[v] = r16 * ROWB + ((((4 * v) + lg) ^ r16) << 4);
 
-    const char* dsrc = reinterpret_cast<const char*>(p.dobuf);
-    auto issue = [&](int64_t o0, int buf) {
-        const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
-        ws_dma_rows<KT, 16, 1>(dsrc + o0 * (int64_t)ROWB, (unsigned)ROWB, ov, raw + buf * RAW);
-    };
     constexpr int NSI = (NST + 511) / 512;
     float stg[NSI][2];
     auto load_stage = [&](int64_t o0) {
@@ -327,7 +330,6 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     };
 
     for (int i = threadIdx.x; i < 2 * XT / 4; i += 512) reinterpret_cast<unsigned int*>(xtra)[i] = 0u;   // padding entries
-    issue(o_beg, 0);
     load_stage(o_beg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
