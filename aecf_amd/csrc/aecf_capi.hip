@@ -3,6 +3,7 @@
 // enqueues the kernels on the caller's stream.  No allocation, no synchronisation, no exceptions.
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/aecf_hip.h"
 #include "aecf_kernels.h"
@@ -180,15 +181,20 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     g.mask_rate = a->mask_rate; g.i_attn_w = a->info_attn_w; g.i_masked_w = a->info_masked_w;
     g.i_entropy = a->info_entropy; g.i_mask_rate = a->info_mask_rate; g.B = d->batch; g.M = M; g.E = E; g.H = H;
     g.mask = make_mask_cfg(d->mask_mode, d->min_active, d->base_mask_prob, d->entropy_target, d->eps, M);
-    launch_gate_fwd(d->dtype, g, s);
-    mark(ev, 2, s);
-
     GemmNtArgs v;
     v.a = a->x; v.w = (const char*)a->w_in + (size_t)2 * E * E * es;
     v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
     v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
     v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = 0; v.v_out = a->saved_v;
+    // bf16, shapes of the weight-stationary kernel, M <= 3: the scores are formed inside the value projection (one pass
+    // over x for both) and the per-sample statistics follow from the saved weights; otherwise the gate kernel runs first
+    static const int no_fuse = getenv("AECF_NO_GATE_FUSION") ? atoi(getenv("AECF_NO_GATE_FUSION")) : 0;   // A/B timing only
+    const bool fuse_gate = d->dtype == AECF_BF16 && M <= 3 && !no_fuse && !getenv("AECF_NO_WS") && gemm_ws_supported(v);
+    if (!fuse_gate) launch_gate_fwd(d->dtype, g, s);
+    mark(ev, 2, s);
+    if (fuse_gate) { v.g_ahi = a_hi; v.g_alo = a_lo; v.g_kpm = a->key_padding_mask; }
     launch_gemm_nt(d->dtype, v, s);
+    if (fuse_gate) launch_gate_stats(d->dtype, g, s);
     mark(ev, 3, s);
 
     GemmNtArgs y;

@@ -46,7 +46,13 @@ __device__ __forceinline__ void ws_dma_rows(const char* __restrict__ src, unsign
     }
 }
 
-template <int KT, int MODE, int M_>
+// GATE (VPROJ only): the softmax weights are PRODUCED here instead of read -- scores x . A[h] against the folded key
+// matrix (bf16 hi/lo split), one more use of the tile that is already in LDS, so the separate gate kernel and its pass
+// over x disappear.  Each wave takes KG = KT/8 K-steps of the score product for all 16 heads x 16 samples x M
+// (2 M KG MFMAs), the partial sums are folded through LDS in wave order, and every wave forms the softmax of ITS head for
+// its lanes' samples (per-lane scalars in this layout).  The per-sample statistics (head mean, curriculum masking)
+// are a tiny follow-up kernel on the saved weights (gate_stats_kernel).
+template <int KT, int MODE, int M_, bool GATE>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
     constexpr int K = 32 * KT, ROWB = 2 * K;
@@ -115,8 +121,32 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     // load beside an in-flight LDS-DMA makes hipcc wait vmcnt(0) in front of the first MFMA, which would serialise
     // the DMA with the compute); the end-of-step s_waitcnt vmcnt(0) retires them with the tile they belong to.
     float pm[MODE == WS_VPROJ ? M_ : 1], pm_next[MODE == WS_VPROJ ? M_ : 1];
+    // GATE: this wave's K-steps of the score product and its operands (rows of A hi/lo = heads), partial-sum buffer
+    constexpr int KG = (KT + 7) / 8;
+    float* gpart = reinterpret_cast<float*>(smem + 2 * TILE);     // [8 waves][M][16 heads][16 samples]
+    u32x4 ga[GATE ? KG : 1][2];
+    if (GATE) {
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int ks = KG * w + kg;                           // waves beyond KT/KG own nothing: zero operands
+            const unsigned short* ah = reinterpret_cast<const unsigned short*>(p.g_ahi) + (int64_t)r16 * K + 32 * ks + 8 * lg;
+            const unsigned short* al = reinterpret_cast<const unsigned short*>(p.g_alo) + (int64_t)r16 * K + 32 * ks + 8 * lg;
+            ga[kg][0] = ks < KT ? *reinterpret_cast<const u32x4*>(ah) : u32x4{0u, 0u, 0u, 0u};
+            ga[kg][1] = ks < KT ? *reinterpret_cast<const u32x4*>(al) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // key_padding_mask bytes of this lane's sample, fetched one step ahead like the probabilities used to be
+    unsigned int kp[GATE ? M_ : 1], kp_next[GATE ? M_ : 1];
     auto load_probs = [&](int64_t o0, float* dst) {
-        if (MODE == WS_VPROJ) {
+        if (MODE == WS_VPROJ && GATE) {
+            if (p.g_kpm) {
+                const int64_t b = (o0 + r16) < o_end ? (o0 + r16) : (o_end - 1);
+                const uint8_t* kq = p.g_kpm + b * M_;
+#pragma unroll
+                for (int m = 0; m < M_; ++m)
+                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(kp_next[m]) : "v"(kq + m) : "memory");
+            }
+        } else if (MODE == WS_VPROJ) {
             const int64_t b = (o0 + r16) < o_end ? (o0 + r16) : (o_end - 1);
             const float* pp = p.probs + (b * H + head) * M_;
 #pragma unroll
@@ -127,12 +157,59 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     load_probs(o_beg, pm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int m = 0; m < (MODE == WS_VPROJ ? M_ : 1); ++m) asm volatile("" : "+v"(pm[m]));
+    for (int m = 0; m < (MODE == WS_VPROJ ? M_ : 1); ++m) {
+        if (GATE) { asm volatile("" : "+v"(kp_next[m])); kp[m] = p.g_kpm ? kp_next[m] : 0u; }
+        else asm volatile("" : "+v"(pm[m]));
+    }
     int cur = 0;
     for (int64_t o0 = o_beg; o0 < o_end; o0 += OROWS, cur ^= 1) {
         __builtin_amdgcn_s_barrier();                              // tile visible to all waves; other buffer free
         if (o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);
         if (o0 + OROWS < o_end) load_probs(o0 + OROWS, pm_next);
+
+        if (GATE) {
+            // ---- scores of this step: partial product over this wave's K-steps, all heads x 16 samples x M
+            const char* tg = smem + cur * TILE;
+            f32x4 gacc[M_];
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                gacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) {
+                    const int ks = (KG * w + kg) % KT;             // (wave-uniform; owners only contribute non-zero)
+                    const int xo = r16 * M_ * ROWB + m * ROWB + ((((ks & 3) * 4 + lg) ^ r16) << 4) + (ks >> 2) * 256;
+                    const u32x4 xf = *reinterpret_cast<const u32x4*>(tg + xo);
+                    gacc[m] = X::mma(ga[kg][0], xf, gacc[m]);
+                    gacc[m] = X::mma(ga[kg][1], xf, gacc[m]);
+                }
+                // accumulator lane (lg, r16), register r: head 4 lg + r, sample r16
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gpart[((w * M_ + m) * 16 + 4 * lg + r) * 16 + r16] = gacc[m][r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // softmax over the modalities for (this wave's head, this lane's sample); partial sums in wave order
+            float sc[M_], mx = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                float a = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) a += gpart[((ww * M_ + m) * 16 + head) * 16 + r16];
+                if (kp[m] != 0u) a = -INFINITY;                   // torch functional.py:6554-6566
+                sc[m] = a;
+                mx = fmaxf(mx, a);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) { sc[m] = expf(sc[m] - mx); sum += sc[m]; }
+            const int64_t bq = o0 + r16;
+            const bool writer = lg == 0 && ncol0 % p.hd == 0 && bq < o_end;         // first wave of the head, one lane per sample
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                pm[m] = sc[m] / sum;
+                if (writer) const_cast<float*>(p.probs)[(bq * H + head) * M_ + m] = pm[m];
+            }
+        }
 
         // ---- products.  One "item" = one LDS operand read + the 2 MFMAs it feeds (the wave's two 16-column tiles).
         //      PLAIN: items run k-major over the two row tiles (4 independent accumulators); VPROJ: modality-major,
@@ -191,8 +268,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tile (and its probabilities) landed
 #pragma unroll
         for (int m = 0; m < (MODE == WS_VPROJ ? M_ : 1); ++m) {
-            asm volatile("" : "+v"(pm_next[m]));
-            pm[m] = pm_next[m];
+            if (GATE) {
+                asm volatile("" : "+v"(kp_next[m]));
+                kp[m] = p.g_kpm ? kp_next[m] : 0u;
+            } else {
+                asm volatile("" : "+v"(pm_next[m]));
+                pm[m] = pm_next[m];
+            }
         }
         // ---- stores: lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + r (c = 0,1; r = 0..3) of row / sample r16
         if (MODE == WS_PLAIN) {
@@ -455,7 +537,7 @@ bool launch_dx2_hk(const BwdGArgs& a, hipStream_t s) {
     }
 }
 
-template <int KT, int MODE, int M_>
+template <int KT, int MODE, int M_, bool GATE>
 void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
     constexpr int RT = MODE == WS_PLAIN ? 2 : M_;
@@ -469,19 +551,20 @@ void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     rpb = (rpb + OROWS - 1) / OROWS * OROWS;
     const int64_t nchunk = (a.R + rpb - 1) / rpb;
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
-    auto kern = gemm_ws_kernel<KT, MODE, M_>;
+    if (GATE) smem += (size_t)8 * M_ * 256 * sizeof(float);
+    auto kern = gemm_ws_kernel<KT, MODE, M_, GATE>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     kern<<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
 }
 
-template <int MODE, int M_>
+template <int MODE, int M_, bool GATE>
 void launch_kt(const GemmNtArgs& a, hipStream_t s) {
     switch (a.K / 32) {
-        case 4: launch_ws<4, MODE, M_>(a, s); break;
-        case 8: launch_ws<8, MODE, M_>(a, s); break;
-        case 12: launch_ws<12, MODE, M_>(a, s); break;
-        default: launch_ws<16, MODE, M_>(a, s); break;
+        case 4: launch_ws<4, MODE, M_, GATE>(a, s); break;
+        case 8: launch_ws<8, MODE, M_, GATE>(a, s); break;
+        case 12: launch_ws<12, MODE, M_, GATE>(a, s); break;
+        default: launch_ws<16, MODE, M_, GATE>(a, s); break;
     }
 }
 
@@ -498,13 +581,13 @@ bool gemm_ws_supported(const GemmNtArgs& a) {
 void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s) {
     if (a.pooled & 1) {
         switch (a.M) {
-            case 1: launch_kt<WS_VPROJ, 1>(a, s); break;
-            case 2: launch_kt<WS_VPROJ, 2>(a, s); break;
-            case 3: launch_kt<WS_VPROJ, 3>(a, s); break;
-            default: launch_kt<WS_VPROJ, 4>(a, s); break;
+            case 1: if (a.g_ahi) launch_kt<WS_VPROJ, 1, true>(a, s); else launch_kt<WS_VPROJ, 1, false>(a, s); break;
+            case 2: if (a.g_ahi) launch_kt<WS_VPROJ, 2, true>(a, s); else launch_kt<WS_VPROJ, 2, false>(a, s); break;
+            case 3: if (a.g_ahi) launch_kt<WS_VPROJ, 3, true>(a, s); else launch_kt<WS_VPROJ, 3, false>(a, s); break;
+            default: if (a.g_ahi) launch_kt<WS_VPROJ, 4, true>(a, s); else launch_kt<WS_VPROJ, 4, false>(a, s); break;
         }
     } else {
-        launch_kt<WS_PLAIN, 1>(a, s);
+        launch_kt<WS_PLAIN, 1, false>(a, s);
     }
 }
 

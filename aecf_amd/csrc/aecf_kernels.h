@@ -44,6 +44,7 @@ struct GateArgs {
     MaskCfg mask;
 };
 void launch_gate_fwd(int dtype, const GateArgs& a, hipStream_t s);
+void launch_gate_stats(int dtype, const GateArgs& a, hipStream_t s);   // head mean + masking from probs (scores fused elsewhere)
 
 // C[r][n] = sum_k A(r,k) W[n][k] + bias[n]
 //   pooled == 0: A(r,k) = a[r*lda + k]
@@ -61,6 +62,11 @@ struct GemmNtArgs {
     int pooled;
     int out_f32;         // store C as float32 regardless of dtype (logits)
     void* v_out;         // pooled only: [R,M,N] dtype, the per-modality products W x_m + bias (or null)
+    // pooled only, optional: produce the softmax weights in the same kernel (scores x . A[h] against the folded key
+    // matrix) instead of reading them; probs is then an OUTPUT.  g_ahi == null: off.
+    const void* g_ahi = nullptr;      // [HPAD,K] dtype
+    const void* g_alo = nullptr;      // [HPAD,K] dtype
+    const uint8_t* g_kpm = nullptr;   // [R,M] or null
 };
 void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
 void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s);   // pooled == 1 path

@@ -307,6 +307,58 @@ void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t 
         transpose_kernel<F32><<<grid, block, 0, s>>>((const float*)src, (float*)dst, E);
 }
 
+// Per-sample statistics from the per-head softmax weights (used when the scores are produced inside the value-projection
+// kernel, aecf_gemm_ws.hip): head mean, curriculum masking, info copies.  One thread per sample; heads summed in order.
+template <typename T, int M_>
+__global__ __launch_bounds__(256) void gate_stats_kernel(GateArgs p) {
+    using X = Tr<T>;
+    typedef typename X::elem elem;
+    const int64_t bs = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (bs >= p.B) return;
+    const int H = p.H;
+    float wsel[M_];
+#pragma unroll
+    for (int m = 0; m < M_; ++m) wsel[m] = 0.f;
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int m = 0; m < M_; ++m) wsel[m] += p.probs[(bs * H + h) * M_ + m];
+    const float invH = 1.0f / (float)H;
+#pragma unroll
+    for (int m = 0; m < M_; ++m) {
+        wsel[m] *= invH;
+        p.attn_w[bs * M_ + m] = wsel[m];
+        if (p.i_attn_w) reinterpret_cast<elem*>(p.i_attn_w)[bs * M_ + m] = X::from_f32(wsel[m]);
+    }
+    if (p.mask.mode != 0) {
+        float w[M_], u[M_], mk[M_];
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            w[m] = wsel[m];
+            u[m] = (p.mask.mode == 1 && p.uniforms) ? p.uniforms[bs * M_ + m] : 0.f;
+        }
+        float ent, rate;
+        unsigned int bits;
+        curriculum_row<M_>(p.mask, M_, w, u, mk, ent, rate, bits);
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            if (p.masked_w) p.masked_w[bs * M_ + m] = mk[m];
+            if (p.i_masked_w) reinterpret_cast<elem*>(p.i_masked_w)[bs * M_ + m] = X::from_f32(mk[m]);
+        }
+        if (p.entropy) p.entropy[bs] = ent;
+        if (p.mask_rate) p.mask_rate[bs] = rate;
+        if (p.i_entropy) reinterpret_cast<elem*>(p.i_entropy)[bs] = X::from_f32(ent);
+        if (p.i_mask_rate) reinterpret_cast<elem*>(p.i_mask_rate)[bs] = X::from_f32(rate);
+    }
+}
+
+void launch_gate_stats(int dtype, const GateArgs& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.B + 255) / 256)), block(256);
+    AECF_DISPATCH_M(a.M, {
+        if (dtype == 0) gate_stats_kernel<BF16, M_><<<grid, block, 0, s>>>(a);
+        else gate_stats_kernel<F32, M_><<<grid, block, 0, s>>>(a);
+    });
+}
+
 void launch_gate_fwd(int dtype, const GateArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.B + 63) / 64)), block(256);
     AECF_DISPATCH_M(a.M, {
