@@ -99,9 +99,12 @@ def test_shapes_fp32(shape, kpm):
 
 @pytest.mark.parametrize("shape", [s for s in SHAPES if (s[2] // s[3]) % 32 == 0],
                          ids=[f"B{b}_M{m}_E{e}_H{h}" for b, m, e, h in SHAPES if (e // h) % 32 == 0])
-def test_shapes_bf16(shape):
+@pytest.mark.parametrize("kpm", [False, True], ids=["nomask", "kpm"])
+def test_shapes_bf16(shape, kpm):
     B, M, E, H = shape
-    errs, agree = _case(B, M, E, H, torch.bfloat16, False, seed=B + M + E + H + 1)
+    if kpm and M == 1:
+        pytest.skip("a single modality cannot be padded away")
+    errs, agree = _case(B, M, E, H, torch.bfloat16, kpm, seed=B + M + E + H + 1)
     tol = 1e-3 + 2.0 ** -8
     for k in ("y", "wbar", "dx"):
         assert errs[k] < tol, (shape, k, errs[k])
