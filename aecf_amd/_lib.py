@@ -17,7 +17,7 @@ AECF_ABI_VERSION = 2
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_FWD_STAGES = 4
-AECF_BWD_STAGES = 7
+AECF_BWD_STAGES = 8
 
 # profiling hook (bench.py): arrays of hipEvent_t handles the next forward / backward call records at its
 # stage boundaries (see include/aecf_hip.h).  None = off (always, outside bench.py).

@@ -121,7 +121,7 @@ const char* aecf_status_string(int status) {
 
 const char* aecf_pool_stage_name(int backward, int stage) {
     static const char* fwd[AECF_FWD_STAGES] = {"prep", "gate", "vproj", "outproj"};
-    static const char* bwd[AECF_BWD_STAGES] = {"prep", "dout", "dw_out", "dscore", "dx", "dw_v", "finalize"};
+    static const char* bwd[AECF_BWD_STAGES] = {"prep", "dout", "dw_out", "dscore", "dx", "dw_v", "u", "finalize"};
     if (stage < 0) return nullptr;
     if (!backward) return stage < AECF_FWD_STAGES ? fwd[stage] : nullptr;
     return stage < AECF_BWD_STAGES ? bwd[stage] : nullptr;
@@ -267,8 +267,12 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     t2.colsum = (float*)(ws + L.cs_v); t2.u = (float*)(ws + L.u_slab); t2.B = B; t2.M = M; t2.E = E; t2.H = H;
     t2.hd = hd; t2.Ej = 0; t2.splits = L.splits; t2.rows_per_split = L.rows_per_split; t2.pooled = 1;
     t2.u_splits = L.u_splits; t2.u_rows_per_split = L.u_rows_per_split;
+    t2.parts = 1;
     launch_gemm_tn(d->dtype, t2, s);
     mark(ev, 6, s);
+    t2.parts = 2;
+    launch_gemm_tn(d->dtype, t2, s);
+    mark(ev, 7, s);
 
     ReduceSegs rs;
     for (int i = 0; i < ReduceSegs::N; ++i) rs.splits[i] = L.splits;
@@ -289,7 +293,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     f.dq_part = (float*)(ws + L.dq_part); f.dw_in = a->dw_in;
     f.db_in = a->db_in; f.dquery = a->dquery; f.E = E; f.H = H; f.hd = hd; f.scale = scale; f.grad_bf16 = gb;
     launch_finalize(d->dtype, f, s);
-    mark(ev, 7, s);
+    mark(ev, 8, s);
     return launch_status();
 }
 

@@ -499,10 +499,11 @@ void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s) {
         if (dtype == 0) launch_gemm_tn_tr(a, s); else launch_wj<F32, 1, false>(a, s);
         return;
     }
-    if (dtype == 0) launch_gemm_tn_tr(a, s);
+    const bool do_main = a.parts != 2, do_u = a.parts != 1;
+    if (dtype == 0 && do_main) launch_gemm_tn_tr(a, s);
     AECF_DISPATCH_M(a.M, {
-        if (dtype == 0) launch_u<BF16, M_>(a, s);
-        else { launch_wj<F32, M_, true>(a, s); launch_u<F32, M_>(a, s); }
+        if (dtype == 0) { if (do_u) launch_u<BF16, M_>(a, s); }
+        else { if (do_main) launch_wj<F32, M_, true>(a, s); if (do_u) launch_u<F32, M_>(a, s); }
     });
 }
 

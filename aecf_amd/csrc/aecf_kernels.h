@@ -119,6 +119,7 @@ struct GemmTnArgs {
     int u_splits;             // the u kernel has its own (finer) batch split: tiny output, needs more blocks
     int64_t u_rows_per_split;
     int pooled;
+    int parts = 0;            // pooled: 0 = main product + u, 1 = main product only, 2 = u only (separate stage timing)
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b64_tr_b16 form (main product only)
