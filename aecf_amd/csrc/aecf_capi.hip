@@ -189,10 +189,13 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     // bf16, shapes of the weight-stationary kernel, M <= 3: the scores are formed inside the value projection (one pass
     // over x for both) and the per-sample statistics follow from the saved weights; otherwise the gate kernel runs first
     static const int no_fuse = getenv("AECF_NO_GATE_FUSION") ? atoi(getenv("AECF_NO_GATE_FUSION")) : 0;   // A/B timing only
-    const bool fuse_gate = d->dtype == AECF_BF16 && M <= 3 && !no_fuse && !getenv("AECF_NO_WS") && gemm_ws_supported(v);
+    bool fuse_gate = d->dtype == AECF_BF16 && M <= 3 && !no_fuse && !getenv("AECF_NO_WS");
+    if (fuse_gate) {
+        v.g_ahi = a_hi; v.g_alo = a_lo; v.g_kpm = a->key_padding_mask;
+        if (!gemm_ws_supported(v)) { fuse_gate = false; v.g_ahi = v.g_alo = nullptr; v.g_kpm = nullptr; }
+    }
     if (!fuse_gate) launch_gate_fwd(d->dtype, g, s);
     mark(ev, 2, s);
-    if (fuse_gate) { v.g_ahi = a_hi; v.g_alo = a_lo; v.g_kpm = a->key_padding_mask; }
     launch_gemm_nt(d->dtype, v, s);
     if (fuse_gate) launch_gate_stats(d->dtype, g, s);
     mark(ev, 3, s);

@@ -52,7 +52,25 @@ __device__ __forceinline__ void ws_dma_rows(const char* __restrict__ src, unsign
 // (2 M KG MFMAs), the partial sums are folded through LDS in wave order, and every wave forms the softmax of ITS head for
 // its lanes' samples (per-lane scalars in this layout).  The per-sample statistics (head mean, curriculum masking)
 // are a tiny follow-up kernel on the saved weights (gate_stats_kernel).
-template <int KT, int MODE, int M_, bool GATE>
+// 4*CT consecutive bf16 output columns of one row: one 16-byte (CT = 2) or 8-byte (CT = 1) store
+template <int CT>
+__device__ __forceinline__ void store_packed(unsigned short* dst, const unsigned int* pk) {
+    if (CT == 2) *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+    else *reinterpret_cast<u32x2*>(dst) = u32x2{pk[0], pk[1]};
+}
+template <int CT>
+__device__ __forceinline__ void store_cols(unsigned short* dst, const float* v) {
+    if (CT == 2) {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                               pack_bf16x2(v[6], v[7])};
+    } else {
+        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+}
+
+// CT = column tiles (of 16) per wave: 2 for K <= 512 (32 columns x K weights = up to 128 VGPRs, a block owns 256 columns),
+// 1 for K = 768 / 1024 (16 columns, a block owns 128).
+template <int KT, int MODE, int M_, bool GATE, int CT>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
     constexpr int K = 32 * KT, ROWB = 2 * K;
@@ -67,8 +85,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     // 1-D grid, XCD-aware: the column groups of one row chunk get ids b, b+8, ... -> same XCD, dispatched together,
     // so the chunk's rows come from HBM once and the other groups read them from that XCD's L2 (aecf_tile.h)
     unsigned int chunk_u, group_u;
-    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(p.N / 256), chunk_u, group_u)) return;
-    const int ncol0 = (int)group_u * 256 + 32 * w;                // this wave's 32 output columns
+    constexpr int CW = 16 * CT, BC = 8 * CW, NV = 4 * CT;        // columns per wave / per block, values per lane and row
+    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(p.N / BC), chunk_u, group_u)) return;
+    const int ncol0 = (int)group_u * BC + CW * w;                 // this wave's output columns
     // output rows (PLAIN) / samples (VPROJ) of this block
     const int64_t o_beg = (int64_t)chunk_u * rows_per_block;
     const int64_t o_all = MODE == WS_PLAIN ? p.R : p.R;           // VPROJ: R counts samples
@@ -91,19 +110,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     // ---- resident weights: MFMA A operand, row i = 4 lg' + r of tile c  <->  column ncol0 + 8 (i >> 2) + 4 c + (i & 3)
     //      (so that accumulator lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + 0..3 of row/sample r16)
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w);
-    u32x4 wreg[KT][2];
+    u32x4 wreg[KT][CT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int n = ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3);
+    for (int c = 0; c < CT; ++c) {
+        const int n = CT == 2 ? ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3) : ncol0 + r16;
         const unsigned short* wr = wsrc + (int64_t)n * K + 8 * lg;
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
     }
-    float bias[8];
+    float bias[NV];
     {
         const unsigned short* bs = reinterpret_cast<const unsigned short*>(p.bias);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bias[j] = bs ? X::to_f32(bs[ncol0 + 8 * lg + j]) : 0.f;
+        for (int j = 0; j < NV; ++j) bias[j] = bs ? X::to_f32(bs[ncol0 + NV * lg + j]) : 0.f;
     }
     const int head = ncol0 / p.hd;                                // VPROJ: the wave's 32 columns lie in one head
 
@@ -226,15 +245,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
             return *reinterpret_cast<const u32x4*>(tb + xaddr[ks & 3] + toff);
         };
         constexpr int NACC = MODE == WS_PLAIN ? RT : 1;
-        f32x4 acc[NACC][2];
+        f32x4 acc[NACC][CT];
 #pragma unroll
         for (int t = 0; t < NACC; ++t)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float ov[8];
-        u32x4 vpk[MODE == WS_VPROJ ? M_ : 1];
+            for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float ov[NV];
+        unsigned int vpk[MODE == WS_VPROJ ? M_ : 1][NV / 2];      // V_m + bias, packed bf16 pairs
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ov[j] = 0.f;
+        for (int j = 0; j < NV; ++j) ov[j] = 0.f;
 
         u32x4 xf[PF + 1];
 #pragma unroll
@@ -246,22 +265,23 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
             const int ks = MODE == WS_PLAIN ? i / RT : i % KT;
             const int t = MODE == WS_PLAIN ? i % RT : 0;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[t][c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[t][c]);
+            for (int c = 0; c < CT; ++c) acc[t][c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[t][c]);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);    // CT MFMA
             if (MODE == WS_VPROJ && ks == KT - 1) {                // modality m = i / KT is complete
                 const int m = i / KT;
-                float v[8];
+                float v[NV];
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < CT; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[4 * c + r] = acc[0][c][r] + bias[4 * c + r];
                         ov[4 * c + r] = fmaf(pm[m], v[4 * c + r], ov[4 * c + r]);
                     }
-                vpk[m] = X::pack(v);
-                acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NV / 2; ++j) vpk[m][j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[0][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 
@@ -276,19 +296,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
                 pm[m] = pm_next[m];
             }
         }
-        // ---- stores: lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + r (c = 0,1; r = 0..3) of row / sample r16
+        // ---- stores: lane (lg, r16) holds columns ncol0 + NV lg + 4 c + r (c < CT; r = 0..3) of row / sample r16
         if (MODE == WS_PLAIN) {
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 const int64_t row = o0 + 16 * t + r16;
-                u32x4 o;
+                float v[NV];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    o[2 * c] = pack_bf16x2(acc[t][c][0] + bias[4 * c], acc[t][c][1] + bias[4 * c + 1]);
-                    o[2 * c + 1] = pack_bf16x2(acc[t][c][2] + bias[4 * c + 2], acc[t][c][3] + bias[4 * c + 3]);
-                }
-                if (row < o_end)
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + 8 * lg) = o;
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[t][c][r] + bias[4 * c + r];
+                if (row < o_end) store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + NV * lg, v);
             }
         } else {
             const int64_t b = o0 + r16;
@@ -296,10 +314,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
                 if (p.v_out) {
 #pragma unroll
                     for (int m = 0; m < M_; ++m)
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.v_out) + (b * M_ + m) * N + ncol0 + 8 * lg) =
-                            vpk[m];
+                        store_packed<CT>(reinterpret_cast<unsigned short*>(p.v_out) + (b * M_ + m) * N + ncol0 + NV * lg, vpk[m]);
                 }
-                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + 8 * lg) = X::pack(ov);
+                store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + NV * lg, ov);
             }
         }
     }
@@ -315,9 +332,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 // the weighting is M*8 FMAs per head on registers: no scaled operand tile, no scaling pass, no second barrier, and the
 // LDS operand traffic of one raw do row per sample instead of M scaled rows.  The key-side term is KX extra MFMA
 // K-steps whose B operand ([ds_hi | ds_lo | ds_hi] entries of the lane's sample) is built in registers.
-template <int KT, int HK, int M_>
+template <int KT, int HK, int M_, int CT>
 __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
+    constexpr int CW = 16 * CT, BC = 8 * CW, NV = 4 * CT;
     constexpr int K = 32 * KT, ROWB = 2 * K;
     constexpr int H_ = KT / HK;                                    // heads
     constexpr int KX = (3 * H_ + 31) / 32;
@@ -333,8 +351,8 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     const int E = p.E;
     unsigned int chunk_u, group_u;
-    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(E / 256), chunk_u, group_u)) return;
-    const int ncol0 = (int)group_u * 256 + 32 * w;
+    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(E / BC), chunk_u, group_u)) return;
+    const int ncol0 = (int)group_u * BC + CW * w;
     const int64_t o_beg = (int64_t)chunk_u * rows_per_block;
     const int64_t o_end = (o_beg + rows_per_block) < p.B ? (o_beg + rows_per_block) : p.B;
     if (o_beg >= o_end) return;
@@ -347,10 +365,10 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     issue(o_beg, 0);                                              // the first rows fly while the weights load
 
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.wvt);
-    u32x4 wreg[KT + KX][2];
+    u32x4 wreg[KT + KX][CT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int n = ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3);
+    for (int c = 0; c < CT; ++c) {
+        const int n = CT == 2 ? ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3) : ncol0 + r16;
         const unsigned short* wr = wsrc + (int64_t)n * K + 8 * lg;
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
@@ -427,9 +445,11 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
         const char* tb = raw + cur * RAW;
         const float* sp = stage + cur * NST + r16 * HM;            // this lane's sample: probs[h][m]
         const char* xq = xtra + cur * XT + r16 * M_ * XROWB + 16 * lg;
-        f32x4 acc[M_][2];
+        f32x4 acc[M_][CT];
 #pragma unroll
-        for (int m = 0; m < M_; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < M_; ++m)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // key-side term first: B operand of modality m = entries [ds_hi | ds_lo | ds_hi] of this lane's sample
 #pragma unroll
@@ -438,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             for (int kx = 0; kx < KX; ++kx) {
                 const u32x4 df = *reinterpret_cast<const u32x4*>(xq + m * XROWB + 64 * kx);
 #pragma unroll
-                for (int c = 0; c < 2; ++c) acc[m][c] = X::mma(wreg[KT + kx][c], df, acc[m][c]);
+                for (int c = 0; c < CT; ++c) acc[m][c] = X::mma(wreg[KT + kx][c], df, acc[m][c]);
             }
 
         // value-side term, head by head; operand reads run PF K-steps ahead
@@ -451,15 +471,16 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
         for (int i = 0; i < PF; ++i) xf[i] = rd(i);
         // software pipeline over heads: the MFMAs of head h+1 are issued in the same scheduling region as the FMAs that
         // apply head h (the matrix pipe and the vector ALU overlap); a scheduling fence per head keeps only two P sets live
-        f32x4 Pc[2], Pn[2];
+        f32x4 Pc[CT], Pn[CT];
         auto head_mma = [&](int h, f32x4* P) {
-            P[0] = P[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < CT; ++c) P[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kl = 0; kl < HK; ++kl) {
                 const int ks = h * HK + kl;
                 if (ks + PF < KT) xf[(ks + PF) % (PF + 1)] = rd(ks + PF);
 #pragma unroll
-                for (int c = 0; c < 2; ++c) P[c] = X::mma(wreg[ks][c], xf[ks % (PF + 1)], P[c]);
+                for (int c = 0; c < CT; ++c) P[c] = X::mma(wreg[ks][c], xf[ks % (PF + 1)], P[c]);
             }
         };
         head_mma(0, Pc);
@@ -470,17 +491,19 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             for (int m = 0; m < M_; ++m) {
                 const float a = sp[h * M_ + m];
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < CT; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[m][c][r] = fmaf(a, Pc[c][r], acc[m][c][r]);
             }
             // keep the weighting of head h HERE (instruction sinking would otherwise move all H*M*8 FMAs behind the last
             // MFMA and keep every head's P live)
 #pragma unroll
-            for (int m = 0; m < M_; ++m) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]));
+            for (int m = 0; m < M_; ++m)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(acc[m][c]));
             __builtin_amdgcn_sched_barrier(0);
-            Pc[0] = Pn[0];
-            Pc[1] = Pn[1];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) Pc[c] = Pn[c];
         }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next do rows + stage values landed
@@ -489,12 +512,12 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
         if (b < o_end) {
 #pragma unroll
             for (int m = 0; m < M_; ++m) {
-                float v[8];
+                float v[NV];
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < CT; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[m][c][r];
-                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.dx) + (b * M_ + m) * E + ncol0 + 8 * lg) = X::pack(v);
+                store_cols<CT>(reinterpret_cast<unsigned short*>(p.dx) + (b * M_ + m) * E + ncol0 + NV * lg, v);
             }
         }
     }
@@ -503,16 +526,20 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
 template <int KT, int HK, int M_>
 void launch_dx2(const BwdGArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
+    constexpr int CT = KT <= 16 ? 2 : 1;
     constexpr int KX = (3 * (KT / HK) + 31) / 32;
     const size_t smem = (size_t)2 * 16 * 2 * K + (size_t)2 * 16 * (KT / HK) * M_ * sizeof(float) + (size_t)2 * 16 * M_ * 64 * KX;
-    const int groups = a.E / 256;
+    const int groups = a.E / (128 * CT);
     int64_t chunks = 256 / groups;
     if (chunks < 1) chunks = 1;
     int64_t rpb = (a.B + chunks - 1) / chunks;
     rpb = (rpb + 15) / 16 * 16;
     const int64_t nchunk = (a.B + rpb - 1) / rpb;
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
-    dx_ws2_kernel<KT, HK, M_><<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
+    auto kern = dx_ws2_kernel<KT, HK, M_, CT>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
 }
 
 template <int KT, int HK>
@@ -525,25 +552,28 @@ void launch_dx2_m(const BwdGArgs& a, hipStream_t s) {
     }
 }
 
+// heads of HK K-steps (head_dim = 32 HK); only the (K, head_dim) pairs with a power-of-two or small head count are built
 template <int KT>
 bool launch_dx2_hk(const BwdGArgs& a, hipStream_t s) {
-    switch (a.hd / 32) {
-        case 1: launch_dx2_m<KT, 1>(a, s); return true;
-        case 2: launch_dx2_m<KT, 2>(a, s); return true;
-        case 4: launch_dx2_m<KT, 4>(a, s); return true;
-        case 8: if (KT >= 8) { launch_dx2_m<KT, (KT >= 8 ? 8 : 1)>(a, s); return true; } return false;
-        case 16: if (KT >= 16) { launch_dx2_m<KT, (KT >= 16 ? 16 : 1)>(a, s); return true; } return false;
-        default: return false;
-    }
+    const int hk = a.hd / 32;
+    if (hk * a.H != KT) return false;
+    if (hk == 1 && KT <= 16) { launch_dx2_m<KT, 1>(a, s); return true; }          // up to 16 heads of 32
+    if (hk == 2 && KT % 2 == 0 && KT <= 32) { launch_dx2_m<KT, (KT % 2 == 0 ? 2 : 1)>(a, s); return true; }
+    if (hk == 3 && KT % 3 == 0) { launch_dx2_m<KT, (KT % 3 == 0 ? 3 : 1)>(a, s); return true; }
+    if (hk == 4 && KT % 4 == 0) { launch_dx2_m<KT, (KT % 4 == 0 ? 4 : 1)>(a, s); return true; }
+    if (hk == 8 && KT % 8 == 0) { launch_dx2_m<KT, (KT % 8 == 0 ? 8 : 1)>(a, s); return true; }
+    if (hk == KT) { launch_dx2_m<KT, KT>(a, s); return true; }                     // a single head
+    return false;
 }
 
 template <int KT, int MODE, int M_, bool GATE>
 void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
+    constexpr int CT = KT <= 16 ? 2 : 1;                           // 32 columns per wave up to K = 512, 16 beyond
     constexpr int RT = MODE == WS_PLAIN ? 2 : M_;
     constexpr int OROWS = MODE == WS_PLAIN ? 32 : 16;
     size_t smem = (size_t)2 * 16 * RT * 2 * K;
-    const int groups = a.N / 256;
+    const int groups = a.N / (128 * CT);
     // about one block per CU (256): chunks of whole steps
     int64_t chunks = 256 / groups;
     if (chunks < 1) chunks = 1;
@@ -552,7 +582,7 @@ void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     const int64_t nchunk = (a.R + rpb - 1) / rpb;
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
     if (GATE) smem += (size_t)8 * M_ * 256 * sizeof(float);
-    auto kern = gemm_ws_kernel<KT, MODE, M_, GATE>;
+    auto kern = gemm_ws_kernel<KT, MODE, M_, GATE, CT>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     kern<<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
@@ -564,17 +594,26 @@ void launch_kt(const GemmNtArgs& a, hipStream_t s) {
         case 4: launch_ws<4, MODE, M_, GATE>(a, s); break;
         case 8: launch_ws<8, MODE, M_, GATE>(a, s); break;
         case 12: launch_ws<12, MODE, M_, GATE>(a, s); break;
-        default: launch_ws<16, MODE, M_, GATE>(a, s); break;
+        case 16: launch_ws<16, MODE, M_, GATE>(a, s); break;
+        case 24: launch_ws<24, MODE, M_, GATE>(a, s); break;
+        default: launch_ws<32, MODE, M_, GATE>(a, s); break;
     }
 }
 
 }  // namespace
 
 // shapes the weight-stationary kernel takes (bf16 only); everything else stays on the tiled kernels
+static bool ws_k_ok(int K) { return K == 128 || K == 256 || K == 384 || K == 512 || K == 768 || K == 1024; }
+
 bool gemm_ws_supported(const GemmNtArgs& a) {
-    if (a.out_f32) return false;
-    if (a.K % 128 != 0 || a.K < 128 || a.K > 512 || a.N % 256 != 0) return false;
-    if (a.pooled & 1) return a.M >= 1 && a.M <= 4 && a.hd % 32 == 0 && a.lda == (int64_t)a.M * a.K;
+    if (a.out_f32 || !ws_k_ok(a.K)) return false;
+    const int ct = a.K <= 512 ? 2 : 1;
+    if (a.N % (128 * ct) != 0) return false;
+    const bool vproj = (a.pooled & 1) != 0;
+    const size_t tile = (size_t)16 * (vproj ? a.M : 2) * 2 * a.K;          // LDS: two tiles (+ the score partials)
+    size_t smem = 2 * tile + (vproj && a.g_ahi ? (size_t)8 * a.M * 1024 : 0);
+    if (smem > 150 * 1024) return false;
+    if (vproj) return a.M >= 1 && a.M <= 4 && a.hd % 32 == 0 && a.lda == (int64_t)a.M * a.K;
     return a.lda == a.K && (a.pooled >> 8) == 0;
 }
 
@@ -595,11 +634,15 @@ void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s) {
 bool launch_dx_ws(const BwdGArgs& a, hipStream_t s) {
     static const int no_ws = getenv("AECF_NO_WS") ? atoi(getenv("AECF_NO_WS")) : 0;
     if (no_ws) return false;
-    if (a.E != 256 && a.E != 512) return false;
     if (a.M < 1 || a.M > 4) return false;
-    if (a.hd % 32 != 0 || a.E != a.H * a.hd) return false;
-    if (a.E == 256) return launch_dx2_hk<8>(a, s);
-    return launch_dx2_hk<16>(a, s);
+    if (a.hd % 32 != 0 || a.E != a.H * a.hd || 16 * a.H * a.M > 1024) return false;
+    switch (a.E) {
+        case 256: return launch_dx2_hk<8>(a, s);
+        case 512: return launch_dx2_hk<16>(a, s);
+        case 768: return launch_dx2_hk<24>(a, s);
+        case 1024: return launch_dx2_hk<32>(a, s);
+        default: return false;
+    }
 }
 
 }  // namespace aecf
