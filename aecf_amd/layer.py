@@ -500,6 +500,8 @@ class MultimodalAttentionPool(nn.Module):
 
         _require_device(key, "key")
         _require_device(query, "query")
+        if batch_size == 0:
+            return self._forward_empty(query, key, tgt_len, src_len, return_info)
         same_kv = (value is key) or (value.data_ptr() == key.data_ptr() and value.shape == key.shape
                                      and value.stride() == key.stride())
         if key.dtype not in _DTYPES:
@@ -569,6 +571,31 @@ class MultimodalAttentionPool(nn.Module):
         if return_info:
             return attn_output, info
         return attn_output
+
+    def _forward_empty(self, query, key, tgt_len, src_len, return_info):
+        """Empty batch (PROBED on the reference: empty outputs with the usual keys, float dtype of the input): no kernel
+        is launched; the outputs stay attached to the parameters so that a backward yields zero gradients."""
+        dt, dev, E = key.dtype, key.device, self.embed_dim
+        a = self.attention
+        zero = (a.in_proj_weight.sum() + a.out_proj.weight.sum() + query.sum() + key.sum()).to(dt) * 0
+        if a.in_proj_bias is not None:
+            zero = zero + (a.in_proj_bias.sum() + a.out_proj.bias.sum()).to(dt) * 0
+        shape = (0, tgt_len, E) if self.batch_first else (tgt_len, 0, E)
+        attn_output = torch.zeros(shape, dtype=dt, device=dev) + zero
+        weights = torch.zeros(0, tgt_len, src_len, dtype=dt, device=dev) + zero
+        info: Dict[str, Any] = {}
+        cm = self.curriculum_masking
+        if cm is not None:
+            z = torch.zeros(0, tgt_len, dtype=dt, device=dev)
+            info.update({'entropy': z, 'mask_rate': z.to(torch.float32) if cm.training else z.clone()})
+            if cm.training:
+                info['target_entropy'] = z.clone()
+            info['attention_weights'] = weights
+            if return_info:
+                info['masked_attention_weights'] = weights.detach()
+        elif return_info:
+            info['attention_weights'] = weights
+        return (attn_output, info) if return_info else attn_output
 
     def _forward_general(self, q_bf, k_bf, v_bf, key_padding_mask, attn_mask, return_info, batch_size, tgt_len,
                          src_len):

@@ -456,3 +456,25 @@ def test_model_missing_modality_training_routes_like_reference_ops():
     assert torch.isfinite(logits).all()
     logits.sum().backward()
     assert model.fusion_query.grad is not None and torch.isfinite(model.fusion_query.grad).all()
+
+
+def test_empty_batch_matches_reference_contract():
+    """PROBED on the reference: an empty batch returns empty tensors with the usual info keys (train and eval)."""
+    import aecf_amd
+    dev = _dev()
+    q, pool = aecf_amd.create_fusion_pool(64, 3, num_heads=2)
+    pool = pool.to(dev)
+    q = torch.nn.Parameter(q.detach().to(dev))
+    x = torch.zeros(0, 3, 64, device=dev, requires_grad=True)
+    pool.train()
+    out, info = pool(q.expand(0, -1, -1), x, return_info=True)
+    assert out.shape == (0, 1, 64)
+    assert {k: tuple(v.shape) for k, v in info.items()} == {
+        "entropy": (0, 1), "mask_rate": (0, 1), "target_entropy": (0, 1), "attention_weights": (0, 1, 3),
+        "masked_attention_weights": (0, 1, 3)}
+    assert info["mask_rate"].dtype == torch.float32
+    out.sum().backward()
+    assert float(pool.attention.in_proj_weight.grad.abs().sum()) == 0.0 and x.grad.shape == (0, 3, 64)
+    pool.eval()
+    out, info = pool(q.expand(0, -1, -1), x, return_info=True)
+    assert set(info) == {"entropy", "mask_rate", "attention_weights", "masked_attention_weights"}
