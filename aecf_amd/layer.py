@@ -514,7 +514,12 @@ class MultimodalAttentionPool(nn.Module):
             q_bf, x = query.transpose(0, 1), key.transpose(0, 1)
         q_base = _shared_query_base(q_bf)
         dropping = self.attention.dropout > 0.0 and self.training
-        if q_base is None or not same_kv or attn_mask is not None or dropping:
+        # shapes the shared-query kernels do not take (more than 8 modalities, more than 16 heads, head sizes that are
+        # not MFMA K-step multiples) are served by the general kernels as long as THEY take them
+        fast_ok = _lib.load().aecf_pool_check(ctypes.byref(_lib.PoolDesc(
+            batch_size, src_len, embed_dim, self.num_heads, _DTYPES[key.dtype], 0, 1, 0.15, 0.7, 1e-8))) == 0
+        general_ok = src_len <= 64 and tgt_len <= 64 and embed_dim % 64 == 0 and embed_dim <= 1024
+        if q_base is None or not same_kv or attn_mask is not None or dropping or (not fast_ok and general_ok):
             # everything outside the shared-query hot path: the general attention kernels
             return self._forward_general(q_bf, x, value if self.batch_first else value.transpose(0, 1),
                                          key_padding_mask, attn_mask, return_info, batch_size, tgt_len, src_len)

@@ -336,9 +336,6 @@ def test_unsupported_configurations_fail_loudly():
     import aecf_amd
     dev = _dev()
     x = torch.randn(4, 3, 64, device=dev)
-    pool8 = aecf_amd.MultimodalAttentionPool(64, num_heads=8).to(dev)           # head_dim 8 on the shared-query path
-    with pytest.raises(RuntimeError, match="not supported"):
-        pool8(torch.randn(1, 1, 64, device=dev).expand(4, -1, -1), x)
     pool = aecf_amd.MultimodalAttentionPool(64, num_heads=2).to(dev)
     with pytest.raises(RuntimeError, match="not supported"):                    # src_len beyond the general kernels
         pool(torch.randn(4, 2, 64, device=dev), torch.randn(4, 65, 64, device=dev))
@@ -346,6 +343,39 @@ def test_unsupported_configurations_fail_loudly():
         pool(torch.randn(4, 2, 64, device=dev), x, attn_mask=torch.zeros(3, 3, device=dev))
     with pytest.raises(NotImplementedError):
         pool(torch.randn(4, 1, 64, device=dev).double(), x.double())            # float64 is not built
+    pool96 = aecf_amd.MultimodalAttentionPool(96, num_heads=2).to(dev)          # E not a multiple of 64: no kernel takes it
+    with pytest.raises(RuntimeError, match="not supported"):
+        pool96(torch.randn(1, 1, 96, device=dev).expand(4, -1, -1), torch.randn(4, 3, 96, device=dev))
+
+
+def test_shapes_outside_the_shared_query_kernels_use_the_general_path():
+    """Head size 8 (not an MFMA K-step multiple) and 12 modalities (> 8): served by the general attention kernels with
+    the shared-query call pattern, against the oracle."""
+    import aecf_amd
+    from oracle import aecf_oracle as O
+    dev = _dev()
+    for (B, M, E, H) in ((40, 3, 64, 8), (24, 12, 128, 4)):
+        g = torch.Generator().manual_seed(B + M)
+        q, pool = aecf_amd.create_fusion_pool(E, M, num_heads=H)
+        pool.curriculum_masking = None
+        pool = pool.to(dev).train()
+        qd = torch.nn.Parameter(q.detach().to(dev))
+        x = torch.randn(B, M, E, generator=g).to(dev).requires_grad_(True)
+        dy = torch.randn(B, 1, E, generator=g)
+        out, info = pool(qd.expand(B, -1, -1), x, return_info=True)
+        (out * dy.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        a = pool.attention
+        cpu = lambda t_: t_.detach().float().cpu()
+        qe = cpu(qd).expand(B, -1, -1)
+        f = O.mha_forward(qe, cpu(x), cpu(x), cpu(a.in_proj_weight), cpu(a.in_proj_bias), cpu(a.out_proj.weight),
+                          cpu(a.out_proj.bias), H)
+        b = O.mha_backward(qe, cpu(x), cpu(x), cpu(a.in_proj_weight), cpu(a.in_proj_bias), cpu(a.out_proj.weight), H, f,
+                           dy, None)
+        assert rel_err(cpu(out), f["y"]) < 1e-5 and rel_err(cpu(info["attention_weights"]), f["wbar"]) < 1e-5
+        assert rel_err(cpu(x.grad), b["dkey"] + b["dvalue"]) < 1e-5
+        assert rel_err(cpu(qd.grad), b["dquery"].sum(0, keepdim=True)) < 1e-5
+        assert rel_err(cpu(a.in_proj_weight.grad), b["dw_in"]) < 1e-5
 
 
 def test_g10_model_step_matches_reference():

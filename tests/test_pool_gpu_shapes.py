@@ -116,11 +116,11 @@ def test_shapes_bf16(shape, kpm):
     assert agree > 0.99
 
 
-def test_bf16_head_dim_16_is_refused():
-    import aecf_amd
-    dev = torch.device("cuda:0")
-    pool = aecf_amd.MultimodalAttentionPool(256, num_heads=16).to(dev, torch.bfloat16)
-    x = torch.randn(8, 3, 256, device=dev, dtype=torch.bfloat16)
-    q = torch.randn(1, 1, 256, device=dev, dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="not supported"):
-        pool(q.expand(8, -1, -1), x)
+def test_bf16_head_dim_16_runs_on_the_general_kernels():
+    """head_dim 16 is not a bf16 MFMA K-step multiple: the shared-query kernels refuse it, the general path serves it."""
+    B, M, E, H = 48, 3, 256, 16
+    errs, agree = _case(B, M, E, H, torch.bfloat16, False, seed=3)
+    # the general path materialises Q, K, V and their gradients in bf16 (as the reference module does in bf16), so it
+    # carries a few more roundings than the collapsed shared-query kernels: 1e-2 of the largest magnitude
+    for k, e in errs.items():
+        assert e < 1e-2, (k, e)
