@@ -16,7 +16,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 inline int esize(int dtype) { return dtype == AECF_BF16 ? 2 : 4; }
 
 struct FwdWs {
-    size_t qs, a_f32, a_hi, a_lo, obuf, total;
+    size_t qs, a_f32, a_hi, a_lo, obuf, wv_frag, wo_frag, total;
 };
 FwdWs fwd_layout(const aecf_pool_desc* d) {
     FwdWs w;
@@ -27,11 +27,14 @@ FwdWs fwd_layout(const aecf_pool_desc* d) {
     w.a_hi = off;  off = align_up(off + HPAD * E * es);
     w.a_lo = off;  off = align_up(off + HPAD * E * es);
     w.obuf = off;  off = align_up(off + (size_t)d->batch * E * es);
+    w.wv_frag = off; off = align_up(off + E * E * es);          // fragment-major W_v, W_o (bf16, weight-stationary kernels)
+    w.wo_frag = off; off = align_up(off + E * E * es);
     w.total = off;
     return w;
 }
 
 struct BwdWs {
+    size_t wvt_frag, wot_frag;
     size_t qs, a_f32, a_hi, a_lo, wvt, wot, dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, dq_part, total;
     int splits, u_splits;
     int64_t rows_per_split, u_rows_per_split;
@@ -67,6 +70,8 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     w.a_lo = off;   off = align_up(off + HPAD * E * es);
     w.wvt = off;    off = align_up(off + E * E * es);
     w.wot = off;    off = align_up(off + E * E * es);
+    w.wvt_frag = off; off = align_up(off + E * E * es);
+    w.wot_frag = off; off = align_up(off + E * E * es);
     w.dobuf = off;  off = align_up(off + B * E * es);
     w.dsbuf = off;  off = align_up(off + B * d->num_heads * d->modalities * 4);
     w.slab_o = off; off = align_up(off + (size_t)S * E * E * 4);
@@ -171,8 +176,16 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
 
     void** ev = a->stage_events;
     mark(ev, 0, s);
+    // fragment-major copies of W_v and W_o for the weight-stationary kernels (bf16, E in {256, 512, 768, 1024})
+    const bool frag = d->dtype == AECF_BF16 && (E == 256 || E == 512 || E == 768 || E == 1024) && !getenv("AECF_NO_WS");
+    FragJobs fj;
+    if (frag) {
+        fj.n = 2;
+        fj.src[0] = (const char*)a->w_in + (size_t)2 * E * E * es; fj.dst[0] = ws + L.wv_frag; fj.transposed[0] = 0;
+        fj.src[1] = a->w_out;                                      fj.dst[1] = ws + L.wo_frag; fj.transposed[1] = 0;
+    }
     launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, a_hi, a_lo, nullptr, nullptr, nullptr, nullptr,
-                    E, H, s);
+                    E, H, fj, s);
     mark(ev, 1, s);
 
     GateArgs g;
@@ -186,6 +199,7 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
     v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
     v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = 0; v.v_out = a->saved_v;
+    if (frag) v.w_frag = ws + L.wv_frag;
     // bf16, shapes of the weight-stationary kernel, M <= 3: the scores are formed inside the value projection (one pass
     // over x for both) and the per-sample statistics follow from the saved weights; otherwise the gate kernel runs first
     static const int no_fuse = getenv("AECF_NO_GATE_FUSION") ? atoi(getenv("AECF_NO_GATE_FUSION")) : 0;   // A/B timing only
@@ -203,6 +217,7 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     GemmNtArgs y;
     y.a = o; y.w = a->w_out; y.bias = a->b_out; y.c = a->y; y.probs = nullptr; y.R = d->batch; y.N = E; y.K = E;
     y.lda = E; y.M = 1; y.H = H; y.hd = hd; y.pooled = 0; y.out_f32 = 0; y.v_out = nullptr;
+    if (frag) y.w_frag = ws + L.wo_frag;
     launch_gemm_nt(d->dtype, y, s);
     mark(ev, 4, s);
     return launch_status();
@@ -234,14 +249,22 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
 
     void** ev = a->stage_events;
     mark(ev, 0, s);
+    const bool frag = d->dtype == AECF_BF16 && (E == 256 || E == 512 || E == 768 || E == 1024) && !getenv("AECF_NO_WS");
+    FragJobs fj;
+    if (frag) {                                       // fragment-major W_v^T (dx) and W_o^T (dout)
+        fj.n = 2;
+        fj.src[0] = w_v;      fj.dst[0] = ws + L.wvt_frag; fj.transposed[0] = 1;
+        fj.src[1] = a->w_out; fj.dst[1] = ws + L.wot_frag; fj.transposed[1] = 1;
+    }
     launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, ws + L.a_hi, ws + L.a_lo, w_v, wvt, a->w_out, wot,
-                    E, H, s);
+                    E, H, fj, s);
     mark(ev, 1, s);
 
     // do = dy W_o   (NT GEMM against W_o^T)
     GemmNtArgs g;
     g.a = a->dy; g.w = wot; g.bias = nullptr; g.c = dobuf; g.probs = nullptr; g.R = B; g.N = E; g.K = E; g.lda = E;
     g.M = 1; g.H = H; g.hd = hd; g.pooled = 0; g.out_f32 = 0; g.v_out = nullptr;
+    if (frag) g.w_frag = ws + L.wot_frag;
     launch_gemm_nt(d->dtype, g, s);
     mark(ev, 2, s);
 
@@ -258,6 +281,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     g2.x = a->x; g2.dobuf = dobuf; g2.wvt = wvt; g2.probs = a->saved_probs; g2.d_attn_w = a->d_attn_w;
     g2.d_entropy = a->d_entropy; g2.attn_w = a->attn_w; g2.dsbuf = dsbuf; g2.a_f32 = a_f32; g2.dx = a->dx;
     g2.B = B; g2.M = M; g2.E = E; g2.H = H; g2.hd = hd; g2.log_M = (float)log((double)M);
+    if (frag) g2.wvt_frag = ws + L.wvt_frag;
     if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
         launch_bwd_g(d->dtype, g2, false, s);      // no saved V (or unsupported head size): recompute W_v^T do per head
     mark(ev, 4, s);

@@ -115,8 +115,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     for (int c = 0; c < CT; ++c) {
         const int n = CT == 2 ? ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3) : ncol0 + r16;
         const unsigned short* wr = wsrc + (int64_t)n * K + 8 * lg;
+        // fragment-major copy (prep kernel): 1 KB contiguous per wave-instruction instead of 16 x 64-byte pieces
+        const u32x4* wf = reinterpret_cast<const u32x4*>(p.w_frag) + ((int64_t)((ncol0 / CW) * CT + c) * KT) * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
+        for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = p.w_frag ? wf[ks * 64] : *reinterpret_cast<const u32x4*>(wr + 32 * ks);
     }
     float bias[NV];
     {
@@ -370,8 +372,9 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     for (int c = 0; c < CT; ++c) {
         const int n = CT == 2 ? ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3) : ncol0 + r16;
         const unsigned short* wr = wsrc + (int64_t)n * K + 8 * lg;
+        const u32x4* wf = reinterpret_cast<const u32x4*>(p.wvt_frag) + ((int64_t)((ncol0 / CW) * CT + c) * KT) * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
+        for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = p.wvt_frag ? wf[ks * 64] : *reinterpret_cast<const u32x4*>(wr + 32 * ks);
 #pragma unroll
         for (int kx = 0; kx < KX; ++kx) {
             float v[8];

@@ -19,10 +19,19 @@ void launch_prep_amat(int dtype, const void* w_in, const float* qs, float* a_f32
                       hipStream_t s);
 // dst[k][j] = src[j][k]   (E x E, dtype)
 void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t s);
-// qs, folded key matrix (f32 + hi/lo) and up to two E x E transposes (t_src* may be null) in one launch
+// up to two fragment-major copies of E x E bf16 weight matrices (optionally of the transpose) for the weight-stationary
+// kernels' prologue (aecf_gemm_ws.hip): done by the same prep launch
+struct FragJobs {
+    int n = 0;
+    const void* src[2] = {nullptr, nullptr};
+    void* dst[2] = {nullptr, nullptr};
+    int transposed[2] = {0, 0};
+};
+// qs, folded key matrix (f32 + hi/lo), up to two E x E transposes (t_src* may be null) and the fragment-major copies
+// in one launch
 void launch_prep_all(int dtype, const void* w_in, const void* b_in, const void* query, float scale, float* qs, float* a_f32,
                      void* a_hi, void* a_lo, const void* t_src0, void* t_dst0, const void* t_src1, void* t_dst1, int E,
-                     int H, hipStream_t s);
+                     int H, const FragJobs& fj, hipStream_t s);
 
 struct GateArgs {
     const void* x;            // [B,M,E]
@@ -64,6 +73,7 @@ struct GemmNtArgs {
     void* v_out;         // pooled only: [R,M,N] dtype, the per-modality products W x_m + bias (or null)
     // pooled only, optional: produce the softmax weights in the same kernel (scores x . A[h] against the folded key
     // matrix) instead of reading them; probs is then an OUTPUT.  g_ahi == null: off.
+    const void* w_frag = nullptr;     // optional fragment-major copy of w (see FragJobs): faster weight prologue
     const void* g_ahi = nullptr;      // [HPAD,K] dtype
     const void* g_alo = nullptr;      // [HPAD,K] dtype
     const uint8_t* g_kpm = nullptr;   // [R,M] or null
@@ -91,6 +101,7 @@ struct BwdGArgs {
     int64_t B;
     int M, E, H, hd;
     float log_M;
+    const void* wvt_frag = nullptr;  // optional fragment-major copy of W_v^T (FragJobs): faster dx weight prologue
 };
 void launch_bwd_g(int dtype, const BwdGArgs& a, bool dx, hipStream_t s);
 // score gradient from the saved value projections: da[b,h,m] = do_h[b] . V_h[b,m]  (memory-bound, one wave per sample)

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
                                                        const typename Tr<T>::elem* __restrict__ t_src0,
                                                        typename Tr<T>::elem* __restrict__ t_dst0,
                                                        const typename Tr<T>::elem* __restrict__ t_src1,
-                                                       typename Tr<T>::elem* __restrict__ t_dst1, int E, int H) {
+                                                       typename Tr<T>::elem* __restrict__ t_dst1, int E, int H, FragJobs fj) {
     using X = Tr<T>;
     typedef typename X::elem elem;
     __shared__ float red[4][64];
@@ -142,6 +142,35 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
     }
     id -= nA;
     const int nt = (E / 32) * (E / 32);
+    const int ntr = (t_src0 ? nt : 0) + (t_src1 ? nt : 0);
+    if (id >= ntr) {
+        // fragment-major copies for the weight-stationary kernels (bf16): chunk ((WG*CT + c)*KT + ks)*64 + lane holds the
+        // 16 bytes MFMA lane (r16, lg) of the wave owning column group WG loads for column tile c, K-step ks -- so that
+        // kernel's weight prologue is 1 KB contiguous per wave-instruction instead of 16 x 64-byte pieces
+        id -= ntr;
+        const int bpj = (E * E / 8 + 255) / 256;                 // blocks per job
+        const int job = id / bpj;
+        const int chunk = (id - job * bpj) * 256 + threadIdx.x;
+        if (job < fj.n && chunk < E * E / 8) {
+            const int CT = E <= 512 ? 2 : 1, KT = E / 32;
+            const int lane = chunk & 63, ks = (chunk >> 6) % KT, rest = (chunk >> 6) / KT;
+            const int c = rest % CT, WG = rest / CT;
+            const int r16 = lane & 15, lg = lane >> 4;
+            const int n = CT == 2 ? 32 * WG + 8 * (r16 >> 2) + 4 * c + (r16 & 3) : 16 * WG + r16;
+            const int k0 = 32 * ks + 8 * lg;
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(fj.src[job]);
+            u32x4 v;
+            if (!fj.transposed[job]) {
+                v = *reinterpret_cast<const u32x4*>(src + (int64_t)n * E + k0);
+            } else {                                              // W^T[n][k0 + j] = W[k0 + j][n]
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    v[d] = (unsigned)src[(int64_t)(k0 + 2 * d) * E + n] | ((unsigned)src[(int64_t)(k0 + 2 * d + 1) * E + n] << 16);
+            }
+            reinterpret_cast<u32x4*>(fj.dst[job])[chunk] = v;
+        }
+        return;
+    }
     const elem* src = id < nt ? t_src0 : t_src1;
     elem* dst = id < nt ? t_dst0 : t_dst1;
     if (id >= nt) id -= nt;
@@ -284,19 +313,20 @@ void launch_prep_amat(int dtype, const void* w_in, const float* qs, float* a_f32
 
 void launch_prep_all(int dtype, const void* w_in, const void* b_in, const void* query, float scale, float* qs, float* a_f32,
                      void* a_hi, void* a_lo, const void* t_src0, void* t_dst0, const void* t_src1, void* t_dst1, int E,
-                     int H, hipStream_t s) {
+                     int H, const FragJobs& fj, hipStream_t s) {
     const int nt = (E / 32) * (E / 32);
-    dim3 grid((E / 64) * HPAD + (t_src0 ? nt : 0) + (t_src1 ? nt : 0)), block(256);
+    const int nfrag = dtype == 0 ? fj.n * ((E * E / 8 + 255) / 256) : 0;
+    dim3 grid((E / 64) * HPAD + (t_src0 ? nt : 0) + (t_src1 ? nt : 0) + nfrag), block(256);
     if (dtype == 0)
         prep_all_kernel<BF16><<<grid, block, 0, s>>>((const unsigned short*)w_in, (const unsigned short*)b_in,
                                                      (const unsigned short*)query, scale, qs, a_f32, (unsigned short*)a_hi,
                                                      (unsigned short*)a_lo, (const unsigned short*)t_src0,
                                                      (unsigned short*)t_dst0, (const unsigned short*)t_src1,
-                                                     (unsigned short*)t_dst1, E, H);
+                                                     (unsigned short*)t_dst1, E, H, fj);
     else
         prep_all_kernel<F32><<<grid, block, 0, s>>>((const float*)w_in, (const float*)b_in, (const float*)query, scale, qs,
                                                     a_f32, (float*)a_hi, (float*)nullptr, (const float*)t_src0,
-                                                    (float*)t_dst0, (const float*)t_src1, (float*)t_dst1, E, H);
+                                                    (float*)t_dst0, (const float*)t_src1, (float*)t_dst1, E, H, FragJobs{});
 }
 
 void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t s) {
