@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
             }
             __syncthreads();
             const elem* wk = w_in + (int64_t)E * E;            // W_k block of the packed in_proj_weight
+#pragma unroll 8
             for (int j = jg; j < hd; j += 4) acc += qsl[j] * X::to_f32(wk[(int64_t)(h * hd + j) * E + k]);
         }
         red[jg][threadIdx.x & 63] = acc;
