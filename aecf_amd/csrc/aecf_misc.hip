@@ -295,8 +295,42 @@ void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat
         modality_frontend_kernel<F32><<<grid, block, 0, s>>>(rows, dim, (const float*)feat, drop, (float*)out, present);
 }
 
+// n up to a few hundred thousand rows: ONE block does both stages (a second launch costs more than the work)
+template <typename T>
+__global__ __launch_bounds__(1024) void entropy_loss_single_kernel(int64_t n, float target, const typename Tr<T>::elem* __restrict__ e,
+                                                                   float scale_grad, float inv_n, float* __restrict__ d_e,
+                                                                   typename Tr<T>::elem* __restrict__ loss) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float raw = Tr<T>::to_f32(e[i]);
+        const float d = nan_to_num_ref(raw) - target;
+        acc += d * d;
+        if (d_e) d_e[i] = isfinite(raw) ? scale_grad * d : 0.f;
+    }
+    acc = reduce_wave(acc);
+    if (lane_id() == 0) red[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        loss[0] = Tr<T>::from_f32(fmaxf(t * inv_n, 0.f));
+    }
+}
+
 void launch_entropy_loss(int dtype, int64_t n, float target, const void* entropy, float upstream, void* loss,
                          float* d_entropy, float* partial, hipStream_t s) {
+    if (n <= (1 << 18)) {
+        const float inv = 1.0f / (float)n;
+        if (dtype == 0)
+            entropy_loss_single_kernel<BF16><<<dim3(1), dim3(1024), 0, s>>>(n, target, (const unsigned short*)entropy,
+                                                                          2.0f * inv * upstream, inv, d_entropy, (unsigned short*)loss);
+        else
+            entropy_loss_single_kernel<F32><<<dim3(1), dim3(1024), 0, s>>>(n, target, (const float*)entropy,
+                                                                         2.0f * inv * upstream, inv, d_entropy, (float*)loss);
+        return;
+    }
     int nblk = (int)((n + 255) / 256);
     if (nblk > 1024) nblk = 1024;
     if (nblk < 1) nblk = 1;
