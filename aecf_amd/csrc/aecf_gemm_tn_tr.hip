@@ -7,7 +7,7 @@
 //     trip, no vector instructions at all;
 //   * rhs tile, plain GEMM: the same;
 //   * rhs tile, POOLED: rhs(b,k) = sum_m probs[b, head(j), m] * x[b,m,k].  Each thread loads two 16-byte chunks of
-//     each modality row, forms the pooled chunk per head slot (v_pk_fma_f32, one v_cvt_pk_bf16_f32 per pair) and
+//     each modality row, forms the pooled chunk per head slot (v_pk_fma_f32 against (p, p) pairs, one v_cvt_pk_bf16_f32 per pair) and
 //     writes it row-major with one ds_write_b128 -- no transposition work;
 //   * lhs column sums (the bias gradients): one extra MFMA against an all-ones operand.
 // LDS image of a [64][128] tile: 8-row x 32-column subtiles of 512 B, 16-byte chunk ch of row r at
@@ -38,8 +38,13 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
 // permutation goes on the per-lane SOURCE address (a wave-instruction still reads 8 rows x 128 contiguous bytes).
 // Rows >= rows_valid re-read the last valid row, chunks >= chunks_valid re-read chunk 0 (in bounds; the caller
 // zeroes or never stores what they produce).  src is wave-uniform; the per-lane part is a 32-bit offset.
-__device__ __forceinline__ void dma_tile_tr(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid,
-                                            int chunks_valid, char* lds) {
+// The copy is issued through inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every transposed LDS read that
+// follows a global_load_lds it can see (the ds_read_tr builtin carries no alias information), which would expose the
+// whole memory latency each step.  The caller retires the copy with its own s_waitcnt vmcnt(0) one step later.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 is named as a clobber on purpose
+__device__ __forceinline__ void dma_tile_tr_async(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid,
+                                                  int chunks_valid, char* lds) {
     const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -49,13 +54,18 @@ __device__ __forceinline__ void dma_tile_tr(const char* __restrict__ src, unsign
         int logical = 4 * ((c >> 5) & 3) + ((c & 3) ^ ((row >> 2) & 3));
         logical = logical < chunks_valid ? logical : 0;
         const unsigned int voff = (unsigned)rowc * ld_bytes + (unsigned)logical * 16u;
-        __builtin_amdgcn_global_load_lds(src + voff, (lds_void_t*)(lds + (wbase + 512 * i) * 16), 16, 0, 0);
+        const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(lds + (wbase + 512 * i) * 16);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(src), "s"(dst) : "memory", "m0");
     }
 }
+#pragma clang diagnostic pop
 
-// NOTE: the pooling below is written with scalar fmaf on purpose and this file is built with -fno-slp-vectorize:
-// the packed form (v_pk_mul_f32 / v_pk_fma_f32 with op_sel broadcast of the probability) gave run-to-run different
-// low halves on MI355X at full size (profiles/r01_pmc_notes.md).
+// NOTE on the pooling arithmetic: the probabilities sit in LDS as (p, p) PAIRS and are used by plain v_pk_mul_f32 /
+// v_pk_fma_f32 (both halves read from their own register).  The form hipcc's SLP vectoriser produced from scalar code
+// -- one register broadcast to both halves through op_sel -- gave run-to-run different low halves on MI355X at full
+// size (profiles/r01_pmc_notes.md); this file is built with -fno-slp-vectorize and the full-size determinism test
+// (tests/test_pool_gpu_large.py) guards the pair form.
 // MFMA operand (8 consecutive batch rows 32 ks + 8 lg .. + 7 of feature column col0 + r16) by two transposed reads
 __device__ __forceinline__ u32x4 tr_frag(const char* tile, int addr_lo, int addr_hi) {
     const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(tile + addr_lo));
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(Gemm
     // LDS carve: lhs tile x2 | rhs tiles (POOLED: one per head slot; plain: x2) | probabilities x2
     char* ldsL = smem;
     char* ldsR = smem + 2 * TR_TILE;
-    float* pl = reinterpret_cast<float*>(ldsR + (POOLED ? MAXS : 2) * TR_TILE);       // [2][TRB][MAXS][M]
+    f32x2* pl = reinterpret_cast<f32x2*>(ldsR + (POOLED ? MAXS : 2) * TR_TILE);       // [TRB][MAXS][M] (p, p) pairs
 
     // wave tile 32 (j) x 64 (k)
     const int j0w = 32 * (w >> 1), k0w = 64 * (w & 1);
@@ -131,104 +141,52 @@ __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(Gemm
 
     // pooling role of this thread: batch row prow, 16-byte chunks pc and pc + 8 of the 128-feature slice
     const int prow = threadIdx.x >> 3, pc = threadIdx.x & 7;
-    const bool c_on[2] = {8 * pc < kcols, 8 * (pc + 8) < kcols};
+    const unsigned int prow_off = (unsigned)prow * ((unsigned)(POOLED ? M_ : 1) * (unsigned)p.E * 2u);
+    const unsigned int coff[2] = {8 * pc < kcols ? 16u * pc : 0u, 8 * (pc + 8) < kcols ? 16u * (pc + 8) : 0u};
     u32x4 Rb[POOLED ? M_ : 1][2];
     float plr[PLN];
 
     auto issue_dma = [&](int64_t base, int buf) {
         const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
-        dma_tile_tr(lhs + base * (int64_t)ldl + (int64_t)j0 * 2, ldl, nvalid, jrows >> 3, ldsL + buf * TR_TILE);
-        if (!POOLED) dma_tile_tr(rhs + base * (int64_t)ldr + (int64_t)k0 * 2, ldr, nvalid, kcols >> 3, ldsR + buf * TR_TILE);
+        dma_tile_tr_async(lhs + base * (int64_t)ldl + (int64_t)j0 * 2, ldl, nvalid, jrows >> 3, ldsL + buf * TR_TILE);
+        if (!POOLED) dma_tile_tr_async(rhs + base * (int64_t)ldr + (int64_t)k0 * 2, ldr, nvalid, kcols >> 3, ldsR + buf * TR_TILE);
     };
-    auto load_regs = [&](int64_t base) {
-        if (POOLED) {
-            const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
-            const float* pu = p.probs + (base * H + h_first) * M_;              // wave-uniform bases, 32-bit lane offsets
-            const char* xu = rhs + base * (int64_t)ldr + (int64_t)k0 * 2;
+    // POOLED operand fetches are inline-asm loads issued ONE STEP AHEAD (hipcc would otherwise wait vmcnt(0) for them
+    // in front of the first transposed read, i.e. expose the whole memory latency every step); the step's own
+    // s_waitcnt vmcnt(0) retires them together with the lhs DMA tile they belong to.
+    auto load_probs = [&](int64_t base) {
+        const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        const float* pu = p.probs + (base * H + h_first) * M_;                  // wave-uniform base, 32-bit lane offsets
 #pragma unroll
-            for (int i = 0; i < PLN; ++i) {
-                const int idx = threadIdx.x + 512 * i;          // (t, s, m) with MAXS slots per row
-                const int t = idx / (MAXS * M_), rem = idx - t * (MAXS * M_);
-                const int sl = rem / M_, m = rem - sl * M_;
-                plr[i] = (idx < TRB * MAXS * M_ && sl < nslots && t < nvalid)
-                             ? pu[(unsigned)(t * H * M_ + sl * M_ + m)] : 0.f;
-            }
-            const unsigned int xoff = (unsigned)prow * ldr + 16u * (unsigned)pc;
-#pragma unroll
-            for (int m = 0; m < M_; ++m)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (c_on[c] && prow < nvalid)
-                        Rb[m][c] = *reinterpret_cast<const u32x4*>(xu + (size_t)m * E * 2 + 128 * c + xoff);
-                    else
-                        Rb[m][c] = u32x4{0u, 0u, 0u, 0u};
-                }
+        for (int i = 0; i < PLN; ++i) {
+            const int idx = threadIdx.x + 512 * i;              // (t, s, m) with MAXS slots per row
+            const int t = idx / (MAXS * M_), rem = idx - t * (MAXS * M_);
+            const int sl = rem / M_, m = rem - sl * M_;
+            const bool on = idx < TRB * MAXS * M_ && sl < nslots && t < nvalid;
+            const float* src = pu + (on ? (unsigned)(t * H * M_ + sl * M_ + m) : 0u);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(plr[i]) : "v"(src) : "memory");
         }
     };
-    auto store_pl = [&](int buf) {
-        if (POOLED) {
+    auto probs_on = [&](int64_t base, int i) -> bool {
+        const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        const int idx = threadIdx.x + 512 * i;
+        const int t = idx / (MAXS * M_), rem = idx - t * (MAXS * M_);
+        return idx < TRB * MAXS * M_ && rem / M_ < nslots && t < nvalid;
+    };
+    // rows past nvalid re-read the last valid row (their probabilities are 0 -> pooled rows of exact zeros); chunks past
+    // kcols re-read chunk 0 (never stored)
+    auto load_x = [&](int64_t base, int c) {
+        const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        const char* xu = rhs + base * (int64_t)ldr + (int64_t)k0 * 2;
+        const unsigned int last = (unsigned)(nvalid - 1) * ldr;
+        const unsigned int roff = (prow_off < last ? prow_off : last) + coff[c];
 #pragma unroll
-            for (int i = 0; i < PLN; ++i) {
-                const int idx = threadIdx.x + 512 * i;
-                if (idx < TRB * MAXS * M_) pl[buf * (TRB * MAXS * M_) + idx] = plr[i];
-            }
+        for (int m = 0; m < M_; ++m) {
+            const char* xm = xu + (size_t)m * E * 2;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(Rb[m][c]) : "v"(roff), "s"(xm) : "memory");
         }
     };
-
-    if (rbeg < rend) {                                    // (a trailing split can be empty: its slab is all zeros)
-        issue_dma(rbeg, 0);
-        load_regs(rbeg);
-        store_pl(0);
-    }
-    int cur = 0;
-    for (int64_t base = rbeg; base < rend; base += TRB, cur ^= 1) {
-        const bool more = base + TRB < rend;
-        const int nvalid_cur = (int)((rend - base) < TRB ? (rend - base) : TRB);
-        __syncthreads();               // MMA of the previous step done; this step's DMA tiles and probabilities visible
-        if (POOLED) {
-            const float* plc = pl + cur * (TRB * MAXS * M_) + prow * (MAXS * M_);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                f32x2 xv[M_][4];
-#pragma unroll
-                for (int m = 0; m < M_; ++m)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        xv[m][i] = f32x2{__uint_as_float(Rb[m][c][i] << 16), __uint_as_float(Rb[m][c][i] & 0xffff0000u)};
-                const int woff = tr_off(prow, pc + 8 * c);
-#pragma unroll
-                for (int sl = 0; sl < MAXS; ++sl) {
-                    if (sl < nslots) {
-                        f32x2 pv[4];
-                        const float p0 = plc[sl * M_];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) pv[i] = f32x2{xv[0][i][0] * p0, xv[0][i][1] * p0};
-#pragma unroll
-                        for (int m = 1; m < M_; ++m) {
-                            const float pm = plc[sl * M_ + m];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) pv[i] = f32x2{fmaf(xv[m][i][0], pm, pv[i][0]), fmaf(xv[m][i][1], pm, pv[i][1])};
-                        }
-                        u32x4 o;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
-                        *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
-                    }
-                }
-            }
-            __syncthreads();                              // pooled tiles visible
-        } else {
-            const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
-            if (nvalid < TRB) {                           // ragged last step: zero the rhs rows that do not exist
-                for (int c = threadIdx.x; c < (TRB - nvalid) * 16; c += 512)
-                    *reinterpret_cast<u32x4*>(ldsR + cur * TR_TILE + tr_off(nvalid + (c >> 4), c & 15)) = u32x4{0u, 0u, 0u, 0u};
-                __syncthreads();
-            }
-        }
-        if (more) {                                       // next step's loads fly behind this step's MFMAs
-            issue_dma(base + TRB, cur ^ 1);
-            load_regs(base + TRB);
-        }
+    auto mma_phase = [&](int cur, int nvalid_cur) {
         if (wave_on) {
             const char* lt = ldsL + cur * TR_TILE;
             const char* rt_tile = ldsR + (POOLED ? wslot : cur) * TR_TILE;
@@ -258,7 +216,93 @@ __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(Gemm
                 }
             }
         }
-        if (more) store_pl(cur ^ 1);
+    };
+
+    if (POOLED) {
+        if (rbeg < rend) {                                // (a trailing split can be empty: its slab is all zeros)
+            issue_dma(rbeg, 0);
+            load_probs(rbeg);
+            load_x(rbeg, 0);
+            load_x(rbeg, 1);
+        }
+        int cur = 0;
+        for (int64_t base = rbeg; base < rend; base += TRB, cur ^= 1) {
+            const bool more = base + TRB < rend;
+            const int nvalid_cur = (int)((rend - base) < TRB ? (rend - base) : TRB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's lhs tile, x chunks and probabilities landed
+#pragma unroll
+            for (int i = 0; i < PLN; ++i) {
+                asm volatile("" : "+v"(plr[i]));
+                const int idx = threadIdx.x + 512 * i;
+                const float pv = probs_on(base, i) ? plr[i] : 0.f;
+                if (idx < TRB * MAXS * M_) pl[idx] = f32x2{pv, pv};
+            }
+#pragma unroll
+            for (int m = 0; m < M_; ++m)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(Rb[m][c]));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // MFMAs of the previous step done; lhs tile + probabilities visible
+            if (more) {
+                issue_dma(base + TRB, cur ^ 1);
+                load_probs(base + TRB);
+            }
+            const f32x2* plc = pl + prow * (MAXS * M_);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x2 xv[M_][4];
+#pragma unroll
+                for (int m = 0; m < M_; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        xv[m][i] = f32x2{__uint_as_float(Rb[m][c][i] << 16), __uint_as_float(Rb[m][c][i] & 0xffff0000u)};
+#pragma unroll
+                for (int m = 0; m < M_; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[m][i]));
+                if (more) load_x(base + TRB, c);          // the chunk registers are free again: next step's chunk flies
+                const int woff = tr_off(prow, pc + 8 * c);
+#pragma unroll
+                for (int sl = 0; sl < MAXS; ++sl) {
+                    if (sl < nslots) {
+                        f32x2 pv[4];
+                        const f32x2 p0 = plc[sl * M_];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pv[i] = xv[0][i] * p0;
+#pragma unroll
+                        for (int m = 1; m < M_; ++m) {
+                            const f32x2 pm = plc[sl * M_ + m];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pv[i] = __builtin_elementwise_fma(xv[m][i], pm, pv[i]);
+                        }
+                        u32x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                        *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // pooled tiles visible
+            mma_phase(cur, nvalid_cur);
+        }
+    } else {
+        if (rbeg < rend) issue_dma(rbeg, 0);
+        int cur = 0;
+        for (int64_t base = rbeg; base < rend; base += TRB, cur ^= 1) {
+            const bool more = base + TRB < rend;
+            const int nvalid_cur = (int)((rend - base) < TRB ? (rend - base) : TRB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's tiles landed (issued one step ago)
+            __builtin_amdgcn_s_barrier();                 // ... for every wave; MFMAs of the previous step done
+            if (nvalid_cur < TRB) {                       // ragged last step: zero the rhs rows that do not exist
+                for (int c = threadIdx.x; c < (TRB - nvalid_cur) * 16; c += 512)
+                    *reinterpret_cast<u32x4*>(ldsR + cur * TR_TILE + tr_off(nvalid_cur + (c >> 4), c & 15)) = u32x4{0u, 0u, 0u, 0u};
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (more) issue_dma(base + TRB, cur ^ 1);     // next step's tiles fly behind this step's MFMAs
+            mma_phase(cur, nvalid_cur);
+        }
     }
 
     // ---- slab stores: acc[rt][ct][r] = out[j0 + j0w + 16 rt + 4 lg + r][k0 + k0w + 16 ct + r16] ----
@@ -286,7 +330,7 @@ __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(Gemm
 template <int M_, bool POOLED, int MAXS>
 void launch_one(const GemmTnArgs& a, hipStream_t s) {
     size_t smem = (size_t)2 * TR_TILE + (size_t)(POOLED ? MAXS : 2) * TR_TILE;
-    if (POOLED) smem += (size_t)2 * TRB * MAXS * M_ * sizeof(float);
+    if (POOLED) smem += (size_t)TRB * MAXS * M_ * 2 * sizeof(float);
     const int nJ = ((a.Ej > 0 ? a.Ej : a.E) + 127) / 128;
     dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)(((a.E + 127) / 128) * nJ))), block(512);
     auto kern = gemm_tn_tr_kernel<M_, POOLED, MAXS>;
