@@ -13,7 +13,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaecf_hip.so")
 
-AECF_ABI_VERSION = 2
+AECF_ABI_VERSION = 3
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_FWD_STAGES = 4
@@ -49,7 +49,7 @@ class PoolFwdArgs(Structure):
         ("saved_o", c_void_p), ("saved_v", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
         ("info_attn_w", c_void_p), ("info_masked_w", c_void_p), ("info_entropy", c_void_p),
-        ("info_mask_rate", c_void_p),
+        ("info_mask_rate", c_void_p), ("saved_prep", c_void_p),
     ]
 
 
@@ -62,7 +62,7 @@ class PoolBwdArgs(Structure):
         ("dquery", c_void_p), ("dw_in", c_void_p), ("db_in", c_void_p), ("dw_out", c_void_p),
         ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
-        ("grad_dtype", c_int32), ("reserved", c_int32),
+        ("grad_dtype", c_int32), ("reserved", c_int32), ("saved_prep", c_void_p),
     ]
 
 
@@ -95,6 +95,7 @@ _SYMBOLS = [
     ("aecf_pool_check", c_int, [POINTER(PoolDesc)]),
     ("aecf_pool_fwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_bwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
+    ("aecf_pool_prep_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_forward", c_int, [POINTER(PoolDesc), POINTER(PoolFwdArgs), c_void_p]),
     ("aecf_pool_backward", c_int, [POINTER(PoolDesc), POINTER(PoolBwdArgs), c_void_p]),
     ("aecf_curriculum_mask_forward", c_int,

@@ -33,9 +33,30 @@ FwdWs fwd_layout(const aecf_pool_desc* d) {
     return w;
 }
 
+// what the backward derives from the parameters alone; lives at the head of the backward workspace or, when the caller
+// passes saved_prep, in that buffer (filled by the forward's preparation launch)
+struct PrepWs {
+    size_t qs, a_f32, a_hi, a_lo, wvt, wot, wvt_frag, wot_frag, total;
+};
+PrepWs prep_layout(const aecf_pool_desc* d) {
+    PrepWs w;
+    const size_t E = d->embed_dim, es = esize(d->dtype);
+    size_t off = 0;
+    w.qs = off;     off = align_up(off + E * 4);
+    w.a_f32 = off;  off = align_up(off + HPAD * E * 4);
+    w.a_hi = off;   off = align_up(off + HPAD * E * es);
+    w.a_lo = off;   off = align_up(off + HPAD * E * es);
+    w.wvt = off;    off = align_up(off + E * E * es);
+    w.wot = off;    off = align_up(off + E * E * es);
+    w.wvt_frag = off; off = align_up(off + E * E * es);
+    w.wot_frag = off; off = align_up(off + E * E * es);
+    w.total = off;
+    return w;
+}
+
 struct BwdWs {
-    size_t wvt_frag, wot_frag;
-    size_t qs, a_f32, a_hi, a_lo, wvt, wot, dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, dq_part, total;
+    PrepWs prep;
+    size_t dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, dq_part, total;
     int splits, u_splits;
     int64_t rows_per_split, u_rows_per_split;
 };
@@ -63,15 +84,8 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
         w.u_splits = (int)((B + urps - 1) / urps);
         w.u_rows_per_split = urps;
     }
-    size_t off = 0;
-    w.qs = off;     off = align_up(off + E * 4);
-    w.a_f32 = off;  off = align_up(off + HPAD * E * 4);
-    w.a_hi = off;   off = align_up(off + HPAD * E * es);
-    w.a_lo = off;   off = align_up(off + HPAD * E * es);
-    w.wvt = off;    off = align_up(off + E * E * es);
-    w.wot = off;    off = align_up(off + E * E * es);
-    w.wvt_frag = off; off = align_up(off + E * E * es);
-    w.wot_frag = off; off = align_up(off + E * E * es);
+    w.prep = prep_layout(d);
+    size_t off = w.prep.total;
     w.dobuf = off;  off = align_up(off + B * E * es);
     w.dsbuf = off;  off = align_up(off + B * d->num_heads * d->modalities * 4);
     w.slab_o = off; off = align_up(off + (size_t)S * E * E * 4);
@@ -156,6 +170,11 @@ size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d) {
     return bwd_layout(d).total;
 }
 
+size_t aecf_pool_prep_bytes(const aecf_pool_desc* d) {
+    if (aecf_pool_check(d) != AECF_OK) return 0;
+    return prep_layout(d).total;
+}
+
 int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream) {
     int st = aecf_pool_check(d);
     if (st != AECF_OK) return st;
@@ -167,10 +186,14 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)a->workspace;
     const int E = d->embed_dim, H = d->num_heads, M = d->modalities, hd = E / H, es = esize(d->dtype);
-    float* qs = (float*)(ws + L.qs);
-    float* a_f32 = (float*)(ws + L.a_f32);
-    void* a_hi = ws + L.a_hi;
-    void* a_lo = ws + L.a_lo;
+    // with saved_prep the parameter-only products go there (the backward reads them back) together with the backward's
+    // own transposes and fragment copies; the forward's fragment copies stay in its workspace
+    const PrepWs P = prep_layout(d);
+    char* pb = (char*)a->saved_prep;
+    float* qs = pb ? (float*)(pb + P.qs) : (float*)(ws + L.qs);
+    float* a_f32 = pb ? (float*)(pb + P.a_f32) : (float*)(ws + L.a_f32);
+    void* a_hi = pb ? (void*)(pb + P.a_hi) : (void*)(ws + L.a_hi);
+    void* a_lo = pb ? (void*)(pb + P.a_lo) : (void*)(ws + L.a_lo);
     void* o = a->saved_o ? a->saved_o : (void*)(ws + L.obuf);
     const float scale = sqrtf(1.0f / (float)hd);     // torch functional.py:6577 q * sqrt(1/head_dim)
 
@@ -183,9 +206,15 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
         fj.n = 2;
         fj.src[0] = (const char*)a->w_in + (size_t)2 * E * E * es; fj.dst[0] = ws + L.wv_frag; fj.transposed[0] = 0;
         fj.src[1] = a->w_out;                                      fj.dst[1] = ws + L.wo_frag; fj.transposed[1] = 0;
+        if (pb) {
+            fj.n = 4;
+            fj.src[2] = fj.src[0]; fj.dst[2] = pb + P.wvt_frag; fj.transposed[2] = 1;
+            fj.src[3] = a->w_out;  fj.dst[3] = pb + P.wot_frag; fj.transposed[3] = 1;
+        }
     }
-    launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, a_hi, a_lo, nullptr, nullptr, nullptr, nullptr,
-                    E, H, fj, s);
+    const char* w_v_src = (const char*)a->w_in + (size_t)2 * E * E * es;
+    launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, a_hi, a_lo, pb ? w_v_src : nullptr,
+                    pb ? pb + P.wvt : nullptr, pb ? a->w_out : nullptr, pb ? pb + P.wot : nullptr, E, H, fj, s);
     mark(ev, 1, s);
 
     GateArgs g;
@@ -237,10 +266,12 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     char* ws = (char*)a->workspace;
     const int E = d->embed_dim, H = d->num_heads, M = d->modalities, hd = E / H, es = esize(d->dtype);
     const int64_t B = d->batch;
-    float* qs = (float*)(ws + L.qs);
-    float* a_f32 = (float*)(ws + L.a_f32);
-    void* wvt = ws + L.wvt;
-    void* wot = ws + L.wot;
+    const PrepWs& P = L.prep;
+    char* pb = a->saved_prep ? (char*)const_cast<void*>(a->saved_prep) : ws;
+    float* qs = (float*)(pb + P.qs);
+    float* a_f32 = (float*)(pb + P.a_f32);
+    void* wvt = pb + P.wvt;
+    void* wot = pb + P.wot;
     void* dobuf = ws + L.dobuf;
     float* dsbuf = (float*)(ws + L.dsbuf);
     float* u = (float*)(ws + L.u);
@@ -251,20 +282,22 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     mark(ev, 0, s);
     const bool frag = d->dtype == AECF_BF16 && (E == 256 || E == 512 || E == 768 || E == 1024) && !getenv("AECF_NO_WS");
     FragJobs fj;
-    if (frag) {                                       // fragment-major W_v^T (dx) and W_o^T (dout)
-        fj.n = 2;
-        fj.src[0] = w_v;      fj.dst[0] = ws + L.wvt_frag; fj.transposed[0] = 1;
-        fj.src[1] = a->w_out; fj.dst[1] = ws + L.wot_frag; fj.transposed[1] = 1;
+    if (!a->saved_prep) {                             // (with saved_prep the forward already produced all of this)
+        if (frag) {                                   // fragment-major W_v^T (dx) and W_o^T (dout)
+            fj.n = 2;
+            fj.src[0] = w_v;      fj.dst[0] = pb + P.wvt_frag; fj.transposed[0] = 1;
+            fj.src[1] = a->w_out; fj.dst[1] = pb + P.wot_frag; fj.transposed[1] = 1;
+        }
+        launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, pb + P.a_hi, pb + P.a_lo, w_v, wvt, a->w_out,
+                        wot, E, H, fj, s);
     }
-    launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, ws + L.a_hi, ws + L.a_lo, w_v, wvt, a->w_out, wot,
-                    E, H, fj, s);
     mark(ev, 1, s);
 
     // do = dy W_o   (NT GEMM against W_o^T)
     GemmNtArgs g;
     g.a = a->dy; g.w = wot; g.bias = nullptr; g.c = dobuf; g.probs = nullptr; g.R = B; g.N = E; g.K = E; g.lda = E;
     g.M = 1; g.H = H; g.hd = hd; g.pooled = 0; g.out_f32 = 0; g.v_out = nullptr;
-    if (frag) g.w_frag = ws + L.wot_frag;
+    if (frag) g.w_frag = pb + P.wot_frag;
     launch_gemm_nt(d->dtype, g, s);
     mark(ev, 2, s);
 
@@ -281,7 +314,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     g2.x = a->x; g2.dobuf = dobuf; g2.wvt = wvt; g2.probs = a->saved_probs; g2.d_attn_w = a->d_attn_w;
     g2.d_entropy = a->d_entropy; g2.attn_w = a->attn_w; g2.dsbuf = dsbuf; g2.a_f32 = a_f32; g2.dx = a->dx;
     g2.B = B; g2.M = M; g2.E = E; g2.H = H; g2.hd = hd; g2.log_M = (float)log((double)M);
-    if (frag) g2.wvt_frag = ws + L.wvt_frag;
+    if (frag) g2.wvt_frag = pb + P.wvt_frag;
     if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
         launch_bwd_g(d->dtype, g2, false, s);      // no saved V (or unsupported head size): recompute W_v^T do per head
     mark(ev, 4, s);

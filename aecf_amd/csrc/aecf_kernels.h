@@ -19,13 +19,13 @@ void launch_prep_amat(int dtype, const void* w_in, const float* qs, float* a_f32
                       hipStream_t s);
 // dst[k][j] = src[j][k]   (E x E, dtype)
 void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t s);
-// up to two fragment-major copies of E x E bf16 weight matrices (optionally of the transpose) for the weight-stationary
+// up to four fragment-major copies of E x E bf16 weight matrices (optionally of the transpose) for the weight-stationary
 // kernels' prologue (aecf_gemm_ws.hip): done by the same prep launch
 struct FragJobs {
     int n = 0;
-    const void* src[2] = {nullptr, nullptr};
-    void* dst[2] = {nullptr, nullptr};
-    int transposed[2] = {0, 0};
+    const void* src[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    int transposed[4] = {0, 0, 0, 0};
 };
 // qs, folded key matrix (f32 + hi/lo), up to two E x E transposes (t_src* may be null) and the fragment-major copies
 // in one launch

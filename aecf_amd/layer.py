@@ -55,6 +55,11 @@ def _require_device(t: torch.Tensor, what: str) -> None:
 # ----------------------------------------------------------------------------------------------
 # autograd bridges (one per C-ABI operator)
 # ----------------------------------------------------------------------------------------------
+# forward prepares the backward's parameter-only operands too (aecf_pool_fwd_args.saved_prep); tests switch it off to
+# compare against the backward's own preparation stage
+_SHARE_PREP = True
+
+
 class _PoolFunction(torch.autograd.Function):
     """aecf_pool_forward / aecf_pool_backward.  Outputs: y [B,E], attn_w [B,M], masked_w [B,M], entropy [B],
     mask_rate [B], all in the activation dtype (the library writes the info tensors in that dtype itself; the
@@ -84,6 +89,9 @@ class _PoolFunction(torch.autograd.Function):
         # per-modality value projections, kept only when a backward will follow (B*M*E elements)
         need_bwd = any(t is not None and t.requires_grad for t in (x, q, w_in, b_in, w_out, b_out))
         saved_v = torch.empty(B, M, E, dtype=dt, device=dev) if need_bwd else None
+        # what the backward derives from the parameters alone is produced by the forward's preparation launch
+        saved_prep = (torch.empty(lib.aecf_pool_prep_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
+                      if (need_bwd and _SHARE_PREP) else None)
         if mask_mode != 0:
             masked_w = torch.empty(B, M, dtype=torch.float32, device=dev)
             entropy = torch.empty(B, dtype=torch.float32, device=dev)
@@ -105,9 +113,9 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(uniforms), _ptr(y), _ptr(attn_w), _ptr(masked_w), _ptr(entropy), _ptr(mask_rate),
             _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(ws), ws_bytes,
             None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd),
-            _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate))
+            _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate), _ptr(saved_prep))
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
-        ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v)
+        ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep)
         ctx.desc = desc
         ctx.q_shape = q.shape
         ctx.param_dtypes = (q.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
@@ -126,7 +134,7 @@ class _PoolFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, d_attn_w, _d_masked, d_entropy, _d_rate):
         lib = _lib.load()
-        xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v = ctx.saved_tensors
+        xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep = ctx.saved_tensors
         desc = ctx.desc
         B, M, E = xc.shape
         dev = xc.device
@@ -153,7 +161,7 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
             _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes,
             None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd),
-            _DTYPES[gdt], 0)
+            _DTYPES[gdt], 0, _ptr(saved_prep))
         _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")
         needs = ctx.needs_input_grad
         return (dx if needs[0] else None,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AECF_ABI_VERSION 2
+#define AECF_ABI_VERSION 3
 
 typedef enum aecf_status {
     AECF_OK = 0,
@@ -93,6 +93,11 @@ typedef struct aecf_pool_fwd_args {
     void* info_masked_w;         /* [B,M] dtype */
     void* info_entropy;          /* [B]   dtype */
     void* info_mask_rate;        /* [B]   dtype */
+    /* optional: aecf_pool_prep_bytes(desc) bytes that receive everything the BACKWARD derives from the parameters alone
+     * (scaled query projection, folded key matrix, W_v^T / W_o^T and their MFMA-fragment copies), produced by the
+     * forward's own preparation launch.  Hand the same buffer to aecf_pool_backward (parameters unchanged in
+     * between -- what autograd guarantees) and its preparation stage disappears.  NULL = off. */
+    void* saved_prep;
 } aecf_pool_fwd_args;
 
 /* Backward (autograd transpose of the above). */
@@ -122,6 +127,7 @@ typedef struct aecf_pool_bwd_args {
      * float32 batch sums are rounded once, in the reduction kernel -- what autograd's cast to a bf16 parameter does) */
     int32_t grad_dtype;
     int32_t reserved;
+    const void* saved_prep;      /* buffer filled by aecf_pool_forward (see aecf_pool_fwd_args.saved_prep) or NULL */
 } aecf_pool_bwd_args;
 
 #define AECF_FWD_STAGES 4   /* prep, gate, vproj, outproj */
@@ -137,6 +143,8 @@ int aecf_pool_check(const aecf_pool_desc* d);
 /* scratch bytes needed by forward / backward for this description */
 size_t aecf_pool_fwd_workspace_bytes(const aecf_pool_desc* d);
 size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d);
+/* bytes of the optional parameter-preparation buffer shared by forward and backward (saved_prep) */
+size_t aecf_pool_prep_bytes(const aecf_pool_desc* d);
 
 int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream);
 int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream);

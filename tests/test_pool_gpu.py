@@ -508,3 +508,17 @@ def test_empty_batch_matches_reference_contract():
     pool.eval()
     out, info = pool(q.expand(0, -1, -1), x, return_info=True)
     assert set(info) == {"entropy", "mask_rate", "attention_weights", "masked_attention_weights"}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shared_preparation_equals_backward_own_preparation(dtype, monkeypatch):
+    """aecf_pool_fwd_args.saved_prep: the backward fed by the forward's preparation launch returns the same bits as
+    the backward that prepares its own operands (include/aecf_hip.h, ABI v3)."""
+    import aecf_amd.layer as layer
+    name = (BF16_CASES if dtype == torch.bfloat16 else FP32_CASES)[0]
+    monkeypatch.setattr(layer, "_SHARE_PREP", True)
+    _, shared = _run_g2(name, dtype)
+    monkeypatch.setattr(layer, "_SHARE_PREP", False)
+    _, own = _run_g2(name, dtype)
+    for k in shared:
+        assert torch.equal(shared[k], own[k]), k
