@@ -50,6 +50,7 @@ class PoolFwdArgs(Structure):
         ("stage_events", c_void_p),
         ("info_attn_w", c_void_p), ("info_masked_w", c_void_p), ("info_entropy", c_void_p),
         ("info_mask_rate", c_void_p), ("saved_prep", c_void_p),
+        ("info_target_entropy", c_void_p), ("target_entropy_value", c_float), ("reserved", c_int32),
     ]
 
 

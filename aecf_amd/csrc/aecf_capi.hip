@@ -221,7 +221,9 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     g.x = a->x; g.a_hi = a_hi; g.a_lo = a_lo; g.kpm = a->key_padding_mask; g.uniforms = a->uniforms;
     g.probs = a->saved_probs; g.attn_w = a->attn_w; g.masked_w = a->masked_w; g.entropy = a->entropy;
     g.mask_rate = a->mask_rate; g.i_attn_w = a->info_attn_w; g.i_masked_w = a->info_masked_w;
-    g.i_entropy = a->info_entropy; g.i_mask_rate = a->info_mask_rate; g.B = d->batch; g.M = M; g.E = E; g.H = H;
+    g.i_entropy = a->info_entropy; g.i_mask_rate = a->info_mask_rate;
+    g.i_target = d->mask_mode == 1 ? a->info_target_entropy : nullptr; g.target_value = a->target_entropy_value;
+    g.B = d->batch; g.M = M; g.E = E; g.H = H;
     g.mask = make_mask_cfg(d->mask_mode, d->min_active, d->base_mask_prob, d->entropy_target, d->eps, M);
     GemmNtArgs v;
     v.a = a->x; v.w = (const char*)a->w_in + (size_t)2 * E * E * es;

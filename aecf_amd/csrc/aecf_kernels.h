@@ -48,6 +48,8 @@ struct GateArgs {
     void* i_masked_w;
     void* i_entropy;
     void* i_mask_rate;
+    void* i_target = nullptr; // [B] activation dtype filled with target_value (info['target_entropy']) or null
+    float target_value = 0.f;
     int64_t B;
     int M, E, H;
     MaskCfg mask;

@@ -295,7 +295,7 @@ void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat
         modality_frontend_kernel<F32><<<grid, block, 0, s>>>(rows, dim, (const float*)feat, drop, (float*)out, present);
 }
 
-// n up to a few hundred thousand rows: ONE block does both stages (a second launch costs more than the work)
+// small n: ONE block does both stages (a second launch costs more than the work)
 template <typename T>
 __global__ __launch_bounds__(1024) void entropy_loss_single_kernel(int64_t n, float target, const typename Tr<T>::elem* __restrict__ e,
                                                                    float scale_grad, float inv_n, float* __restrict__ d_e,
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void entropy_loss_single_kernel(int64_t n, fl
 
 void launch_entropy_loss(int dtype, int64_t n, float target, const void* entropy, float upstream, void* loss,
                          float* d_entropy, float* partial, hipStream_t s) {
-    if (n <= (1 << 18)) {
+    if (n <= 8192) {       // (one block walks n/1024 dependent rounds: beyond a few thousand rows two launches win)
         const float inv = 1.0f / (float)n;
         if (dtype == 0)
             entropy_loss_single_kernel<BF16><<<dim3(1), dim3(1024), 0, s>>>(n, target, (const unsigned short*)entropy,

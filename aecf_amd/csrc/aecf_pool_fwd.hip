@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(GateArgs p) {
                 }
                 if (p.i_entropy) reinterpret_cast<elem*>(p.i_entropy)[bs] = X::from_f32(ent);
                 if (p.i_mask_rate) reinterpret_cast<elem*>(p.i_mask_rate)[bs] = X::from_f32(rate);
+                if (p.i_target) reinterpret_cast<elem*>(p.i_target)[bs] = X::from_f32(p.target_value);
             }
         }
     }
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(GateArgs p) {
         if (p.mask_rate) p.mask_rate[bs] = rate;
         if (p.i_entropy) reinterpret_cast<elem*>(p.i_entropy)[bs] = X::from_f32(ent);
         if (p.i_mask_rate) reinterpret_cast<elem*>(p.i_mask_rate)[bs] = X::from_f32(rate);
+        if (p.i_target) reinterpret_cast<elem*>(p.i_target)[bs] = X::from_f32(p.target_value);
     }
 }
 

@@ -67,7 +67,7 @@ class _PoolFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, q, w_in, b_in, w_out, b_out, kpm, uniforms, num_heads, mask_mode, min_active,
-                base_mask_prob, entropy_target, eps, f32_info=False):
+                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)       # unused outputs arrive as None, not as zero tensors (fill + cast launches)
         B, M, E = x.shape
@@ -106,6 +106,8 @@ class _PoolFunction(torch.autograd.Function):
             i_mask_rate = None if (mask_rate is None or mask_mode == 1) else torch.empty(B, dtype=dt, device=dev)
         else:
             i_attn_w = i_masked_w = i_entropy = i_mask_rate = None
+        # info['target_entropy'] (ref :273), filled by the kernel that writes the other info tensors
+        i_target = torch.empty(B, dtype=dt, device=dev) if (mask_mode == 1 and target_value is not None) else None
         ws_bytes = lib.aecf_pool_fwd_workspace_bytes(ctypes.byref(desc))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolFwdArgs(
@@ -113,7 +115,8 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(uniforms), _ptr(y), _ptr(attn_w), _ptr(masked_w), _ptr(entropy), _ptr(mask_rate),
             _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(ws), ws_bytes,
             None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd),
-            _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate), _ptr(saved_prep))
+            _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate), _ptr(saved_prep),
+            _ptr(i_target), 0.0 if target_value is None else float(target_value), 0)
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
         ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep)
         ctx.desc = desc
@@ -122,17 +125,17 @@ class _PoolFunction(torch.autograd.Function):
                             None if b_out is None else b_out.dtype)
         ctx.has_bias = (b_in is not None, b_out is not None)
         if i_attn_w is not None:
-            outs = (y, i_attn_w, i_masked_w, i_entropy, mask_rate if mask_mode == 1 else i_mask_rate)
+            outs = (y, i_attn_w, i_masked_w, i_entropy, mask_rate if mask_mode == 1 else i_mask_rate, i_target)
         else:
-            outs = (y, attn_w, masked_w, entropy, mask_rate)
-        nondiff = [t for t in (outs[2], outs[4]) if t is not None]
+            outs = (y, attn_w, masked_w, entropy, mask_rate, i_target)
+        nondiff = [t for t in (outs[2], outs[4], outs[5]) if t is not None]
         if outs[3] is not None and mask_mode == 1:
             nondiff.append(outs[3])            # train mode: entropy is detached (ref :278)
         ctx.mark_non_differentiable(*nondiff)
         return outs
 
     @staticmethod
-    def backward(ctx, dy, d_attn_w, _d_masked, d_entropy, _d_rate):
+    def backward(ctx, dy, d_attn_w, _d_masked, d_entropy, _d_rate, _d_target=None):
         lib = _lib.load()
         xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep = ctx.saved_tensors
         desc = ctx.desc
@@ -170,7 +173,7 @@ class _PoolFunction(torch.autograd.Function):
                 db_in.to(bid) if (ctx.has_bias[0] and needs[3]) else None,
                 dw_out.to(wod) if needs[4] else None,
                 db_out.to(bod) if (ctx.has_bias[1] and needs[5]) else None,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 class _MaskFunction(torch.autograd.Function):
@@ -548,10 +551,12 @@ class MultimodalAttentionPool(nn.Module):
                 # one float32 uniform per weight element, row-major, default generator (ref :204)
                 uniforms = _draw_uniforms((batch_size, tgt_len, src_len), x.device)
         a = self.attention
-        y, attn_w, masked_w, entropy, mask_rate = _PoolFunction.apply(
+        tgt_value = math.log(float(src_len)) * cm.entropy_target if mask_mode == 1 else None        # ref :273
+        y, attn_w, masked_w, entropy, mask_rate, tgt_entropy = _PoolFunction.apply(
             x, q_base, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, kpm, uniforms,
             self.num_heads, mask_mode, 1 if cm is None else int(cm.min_active),
-            0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8)
+            0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8,
+            False, tgt_value)
 
         dt = x.dtype
         attn_output = y.unsqueeze(1) if self.batch_first else y.unsqueeze(0)          # [B,1,E] / [1,B,E]
@@ -569,7 +574,7 @@ class MultimodalAttentionPool(nn.Module):
                 mask_info = {
                     'entropy': ent,
                     'mask_rate': mask_rate.unsqueeze(1),                             # float32 (ref :275)
-                    'target_entropy': torch.full_like(ent, math.log(float(src_len)) * cm.entropy_target),
+                    'target_entropy': tgt_entropy.unsqueeze(1),
                 }
                 masked_weights = masked_w.to(dt).unsqueeze(1)
             else:

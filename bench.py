@@ -237,7 +237,7 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
         # corrected as MI355X_MICROARCH.md prescribes); null when no counter pass exists for this config
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"r01_v6_{args.config}_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", f"r01_v7_{args.config}_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f)["bytes_per_launch"].get(dom)

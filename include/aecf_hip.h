@@ -98,6 +98,11 @@ typedef struct aecf_pool_fwd_args {
      * forward's own preparation launch.  Hand the same buffer to aecf_pool_backward (parameters unchanged in
      * between -- what autograd guarantees) and its preparation stage disappears.  NULL = off. */
     void* saved_prep;
+    /* optional (mask_mode 1): info['target_entropy'] of the reference (ref :273, full_like(entropy, log(M) * target)):
+     * [B] dtype filled with target_entropy_value by the kernel that writes the other info tensors; NULL = not wanted */
+    void* info_target_entropy;
+    float target_entropy_value;  /* the caller's log(M) * entropy_target, rounded to float32 */
+    int32_t reserved;
 } aecf_pool_fwd_args;
 
 /* Backward (autograd transpose of the above). */

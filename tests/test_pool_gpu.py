@@ -105,7 +105,7 @@ def test_pool_bf16_float32_statistics():
     dev = _dev()
     B, H = int(g["B"]), int(g["H"])
     bf = torch.bfloat16
-    y, attn_w, _, _, _ = _PoolFunction.apply(
+    y, attn_w, _, _, _, _ = _PoolFunction.apply(
         t(g["x"]).to(dev, bf), t(g["query"]).to(dev, bf), t(g["w_in"]).to(dev, bf), t(g["b_in"]).to(dev, bf),
         t(g["w_out"]).to(dev, bf), t(g["b_out"]).to(dev, bf), None, None, H, 0, 1, 0.15, 0.7, 1e-8, True)
     e = rel_err(attn_w.cpu().reshape(B, 1, -1), g["wbar"])
@@ -321,7 +321,7 @@ def test_fused_mask_equals_oracle_on_kernel_weights():
     U = torch.rand(B, M, generator=gen)
     for dtype in (torch.float32, torch.bfloat16):
         for p_base, k in ((0.15, 1), (1.0, 1), (0.7, 2)):
-            y, attn_w, masked, ent, rate = _PoolFunction.apply(
+            y, attn_w, masked, ent, rate, _ = _PoolFunction.apply(
                 x.to(dev, dtype), q.to(dev, dtype), w_in.to(dev, dtype), None, w_out.to(dev, dtype), None, None,
                 U.to(dev), H, 1, k, p_base, 0.7, 1e-8, True)
             r = O.curriculum_mask_train(attn_w.cpu(), U, p_base, 0.7, k)
