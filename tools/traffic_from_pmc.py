@@ -1,7 +1,7 @@
 """HBM bytes per launch per bench stage from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs).
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB and gfx950 reports half of wide streaming reads
 (MI355X_MICROARCH.md, HBM / rocprofv3 section).   usage: traffic_from_pmc.py <fetch_dir> <write_dir> <config> <out.json>"""
-import csv, glob, json, re, sys, collections
+import csv, glob, json, re, sqlite3, sys, collections
 
 STAGE = [  # (regex on the kernel name, stage)
     (r"gate_fwd_kernel", "fwd.gate"),
@@ -17,11 +17,16 @@ STAGE = [  # (regex on the kernel name, stage)
 
 
 def per_kernel(d, counter):
+    """average counter value per kernel name, from rocprofv3's csv output or its rocpd sqlite output"""
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for f in glob.glob(d + "/**/*_results.db", recursive=True):
+        db = sqlite3.connect(f)
+        for name, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            acc[name].append(float(value))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
