@@ -89,6 +89,54 @@ class FlatGradBucket:
         return works
 
 
+def flat_grad_alias(params: Iterable[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+    """The fusion layer's backward writes its five parameter gradients into ONE allocation (aecf_amd/layer.py:
+    _PoolFunction.backward) and autograd keeps those tensors as ``p.grad`` without copying.  If the gradients of
+    ``params`` tile one contiguous run of a single storage, return that run as a flat tensor (so the whole set
+    travels as one in-place collective with no zero / accumulate / copy kernels around it); otherwise None."""
+    grads = [p.grad for p in params if p.requires_grad]
+    if not grads or any(g is None for g in grads):
+        return None
+    g0 = grads[0]
+    st = g0.untyped_storage()
+    for g in grads:
+        if g.untyped_storage().data_ptr() != st.data_ptr() or g.dtype != g0.dtype or not g.is_contiguous():
+            return None
+    spans = sorted((g.storage_offset(), g.numel()) for g in grads)
+    off = spans[0][0]
+    for o, n in spans:
+        if o != off:                                  # a gap or an overlap: not one run
+            return None
+        off += n
+    return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(st, spans[0][0], (off - spans[0][0],))
+
+
+def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = True):
+    """One collective for the gradients of ``params``: in place over their shared allocation when they alias one
+    (see flat_grad_alias), else through a temporary flat copy.  RCCL averages inside the collective (ReduceOp.AVG);
+    gloo sums and the division follows."""
+    params = [p for p in params if p.requires_grad and p.grad is not None]
+    _, world = world_info(group)
+    if world == 1 or not params:
+        return
+    flat = flat_grad_alias(params)
+    copied = flat is None
+    if copied:
+        flat = torch.cat([p.grad.reshape(-1).to(params[0].grad.dtype) for p in params])
+    if average and dist.get_backend(group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat.div_(world)
+    if copied:
+        off = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+
 class _AllGatherRows(torch.autograd.Function):
     """z_local [b, d] -> z_all [sum b, d] (rank order); backward: each rank keeps the gradient rows of its own
     shard summed over ranks (reduce-scatter; all-reduce + slice where the backend has no reduce_scatter)."""

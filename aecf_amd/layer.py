@@ -152,11 +152,11 @@ class _PoolFunction(torch.autograd.Function):
         # its float32 batch sums once), float32 otherwise (e.g. float32 master weights under bf16 activations)
         qd, wid, bid, wod, bod = ctx.param_dtypes
         gdt = dt if all(p is None or p == dt for p in ctx.param_dtypes) else torch.float32
-        dquery = torch.empty(E, dtype=gdt, device=dev)
-        dw_in = torch.empty(3 * E, E, dtype=gdt, device=dev)
-        db_in = torch.empty(3 * E, dtype=gdt, device=dev)
-        dw_out = torch.empty(E, E, dtype=gdt, device=dev)
-        db_out = torch.empty(E, dtype=gdt, device=dev)
+        # one allocation for the five of them: autograd keeps these tensors as p.grad without copying, so a data-parallel
+        # caller can all-reduce the whole run in place with a single collective (aecf_amd/dp.py: all_reduce_grads)
+        flat = torch.empty(4 * E * E + 5 * E, dtype=gdt, device=dev)
+        dquery, dw_in, db_in, dw_out, db_out = flat.split([E, 3 * E * E, 3 * E, E * E, E])
+        dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
         ws_bytes = lib.aecf_pool_bwd_workspace_bytes(ctypes.byref(desc))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolBwdArgs(

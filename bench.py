@@ -51,21 +51,20 @@ def make_inputs(cfg, device):
     return pool, query, x, dy
 
 
-def step(pool, query, x, dy, params, bucket):
+def step(pool, query, x, dy, params, dp_on):
     """One pass of the hot path over one resident batch: forward (+ entropy_loss) + backward (+ the one
     gradient all-reduce when data-parallel)."""
     B = x.shape[0]
     out, info = pool(query.expand(B, -1, -1), x, return_info=True)
     ent_loss = pool.curriculum_masking.entropy_loss(info["entropy"])
     x.grad = None
-    if bucket is None:
-        for p in params:
-            p.grad = None
-    else:
-        bucket.zero()                       # parameter gradients accumulate straight into the flat bucket
+    for p in params:
+        p.grad = None
     torch.autograd.backward([out], [dy])
-    if bucket is not None:
-        bucket.all_reduce(average=True)     # ONE RCCL all-reduce of 4E^2+5E values
+    if dp_on:
+        # ONE RCCL all-reduce (AVG) of the 4E^2+5E values, in place over the allocation the backward wrote them into
+        from aecf_amd.dp import all_reduce_grads
+        all_reduce_grads(params)
     return out, ent_loss
 
 
@@ -195,10 +194,7 @@ def main():
     B, M, E, H, dtype, p = cfg
     pool, query, x, dy = make_inputs(cfg, device)
     params = [query] + list(pool.parameters())
-    bucket = None
-    if world > 1:
-        from aecf_amd.dp import FlatGradBucket
-        bucket = FlatGradBucket(params)
+    bucket = world > 1                      # data-parallel: gradients are all-reduced inside the step
 
     def barrier():
         if world > 1:
@@ -227,7 +223,7 @@ def main():
         st = StageTimer()
         for _ in range(min(args.steps, 20)):
             st.arm()
-            step(pool, query, x, dy, params, None)
+            step(pool, query, x, dy, params, False)
             st.disarm()
             torch.cuda.synchronize()
             st.collect()

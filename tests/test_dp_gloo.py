@@ -114,3 +114,74 @@ def test_flat_bucket_views_and_single_process():
     assert bucket.all_reduce() == []                            # world 1: nothing to do
     bucket.zero()
     assert float(flat.abs().sum()) == 0.0
+
+
+class _OneAllocationGrads(torch.autograd.Function):
+    """Stands in for the fusion layer's backward: the parameter gradients are slices of ONE allocation
+    (aecf_amd/layer.py:_PoolFunction.backward), which autograd keeps as p.grad without copying."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ctx.save_for_backward(x, a, b)
+        return x @ a + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a, b = ctx.saved_tensors
+        flat = torch.empty(a.numel() + b.numel())
+        da, db = flat.split([a.numel(), b.numel()])
+        da, db = da.view_as(a), db.view_as(b)
+        torch.matmul(x.t(), g, out=da)
+        torch.sum(g, 0, out=db)
+        return None, da, db
+
+
+def _alias_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        B = 10
+        x = torch.randn(B, 6)
+        a = torch.nn.Parameter(torch.randn(6, 4))
+        b = torch.nn.Parameter(torch.randn(4))
+        extra = torch.nn.Parameter(torch.randn(4))             # a parameter whose gradient lives elsewhere
+        lo, hi = dp.shard_bounds(B, rank, world)
+        (_OneAllocationGrads.apply(x[lo:hi], a, b).sum() / B * world).backward()
+        aliased = dp.flat_grad_alias([a, b]) is not None
+        ptr = a.grad.data_ptr()
+        dp.all_reduce_grads([a, b])                              # in place over the shared allocation
+        in_place = a.grad.data_ptr() == ptr
+        # fallback: gradients that do not tile one allocation travel through a flat copy
+        a2 = torch.nn.Parameter(a.detach().clone())
+        ((x[lo:hi] @ a2 + extra).sum() / B * world).backward()
+        not_aliased = dp.flat_grad_alias([a2, extra]) is None
+        dp.all_reduce_grads([a2, extra])
+        q.put((rank, aliased, in_place, not_aliased, a.grad.numpy(), b.grad.numpy(), a2.grad.numpy(), extra.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_all_reduce_grads_in_place_over_one_allocation():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_alias_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    x = torch.randn(10, 6)
+    da = x.sum(0, keepdim=True).t().expand(6, 4) / 10           # d/da of mean over the batch of sum(x a + b)
+    for rank, aliased, in_place, not_aliased, ga, gb, ga2, gextra in res:
+        assert aliased and in_place and not_aliased
+        assert torch.allclose(torch.from_numpy(ga), da, atol=1e-6)                    # averaged over ranks == full batch
+        assert torch.allclose(torch.from_numpy(gb), torch.ones(4), atol=1e-6)
+        assert torch.allclose(torch.from_numpy(ga2), da, atol=1e-6)
+        assert torch.allclose(torch.from_numpy(gextra), torch.ones(4), atol=1e-6)

@@ -522,3 +522,25 @@ def test_shared_preparation_equals_backward_own_preparation(dtype, monkeypatch):
     _, own = _run_g2(name, dtype)
     for k in shared:
         assert torch.equal(shared[k], own[k]), k
+
+
+def test_parameter_gradients_share_one_allocation():
+    """The five parameter gradients come out of the backward as slices of one allocation and autograd keeps them
+    without copying, so dp.all_reduce_grads sends them as ONE in-place collective (aecf_amd/dp.py)."""
+    from aecf_amd import dp
+    g = load_npz(BF16_CASES[0])
+    dev = _dev()
+    B, E = int(g["B"]), int(g["E"])
+    pool = _build_pool(g, torch.bfloat16)
+    pool.train()
+    x = t(g["x"]).to(dev, torch.bfloat16).requires_grad_(True)
+    q0 = torch.nn.Parameter(t(g["query"]).to(dev, torch.bfloat16))
+    y, _ = pool(q0.expand(B, -1, -1), x, return_info=True)
+    y.float().sum().backward()
+    params = [q0] + list(pool.parameters())
+    flat = dp.flat_grad_alias(params)
+    assert flat is not None and flat.numel() == 4 * E * E + 5 * E
+    assert flat.data_ptr() == q0.grad.data_ptr()
+    before = [p.grad.clone() for p in params]
+    dp.all_reduce_grads(params)                                  # world 1: a no-op
+    assert all(torch.equal(a, p.grad) for a, p in zip(before, params))
