@@ -84,15 +84,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
             char* curA = ldsA + (kt & 1) * 2 * TILE;
             char* curB = ldsB + (kt & 1) * 2 * TILE;
             __syncthreads();
-            if (kt + 1 < nkt && !(p.pooled & 1024)) {
+            if (kt + 1 < nkt) {
                 const int64_t koff = (int64_t)(kt + 1) * TILE_ROW_BYTES;
                 dma_tile<128, 256>(a_src + koff, lda_bytes, rows_valid, ldsA + ((kt + 1) & 1) * 2 * TILE);
                 dma_tile<128, 256>(w_src + koff, ldw_bytes, cols_valid, ldsB + ((kt + 1) & 1) * 2 * TILE);
             }
-            if (!(p.pooled & 512)) tile_mma<T, 4, 4>(acc, curA, 64 * wr, curB, 64 * wc);
+            tile_mma<T, 4, 4>(acc, curA, 64 * wr, curB, 64 * wc);
         }
     }
-    if (p.pooled & 256) return;
     // ---------------- epilogue ----------------
     const elem* bias = reinterpret_cast<const elem*>(p.bias);
     float bv[4];
@@ -167,8 +166,6 @@ static void launch_one(const GemmNtArgs& a, hipStream_t s) {
 
 void launch_gemm_nt(int dtype, const GemmNtArgs& a_in, hipStream_t s) {
     GemmNtArgs a = a_in;
-    static const int dbg = getenv("AECF_GEMM_DEBUG") ? atoi(getenv("AECF_GEMM_DEBUG")) : 0;   // timing experiments only
-    if (!(a.pooled & 1)) a.pooled |= dbg << 8;
     static const int no_ws = getenv("AECF_NO_WS") ? atoi(getenv("AECF_NO_WS")) : 0;              // A/B timing only
     if (dtype == 0 && !no_ws && gemm_ws_supported(a)) { launch_gemm_ws(a, s); return; }   // aecf_gemm_ws.hip
     if (a.pooled & 1) { launch_vproj(dtype, a, s); return; }     // per-modality accumulators (aecf_vproj.hip)

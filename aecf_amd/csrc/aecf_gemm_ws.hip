@@ -617,7 +617,7 @@ bool gemm_ws_supported(const GemmNtArgs& a) {
     size_t smem = 2 * tile + (vproj && a.g_ahi ? (size_t)8 * a.M * 1024 : 0);
     if (smem > 150 * 1024) return false;
     if (vproj) return a.M >= 1 && a.M <= 4 && a.hd % 32 == 0 && a.lda == (int64_t)a.M * a.K;
-    return a.lda == a.K && (a.pooled >> 8) == 0;
+    return a.lda == a.K;
 }
 
 void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s) {

@@ -124,3 +124,36 @@ def test_bf16_head_dim_16_runs_on_the_general_kernels():
     # carries a few more roundings than the collapsed shared-query kernels: 1e-2 of the largest magnitude
     for k, e in errs.items():
         assert e < 1e-2, (k, e)
+
+
+_FALLBACK_SCRIPT = r"""
+import json, sys, torch
+sys.path.insert(0, {root!r})
+from tests.test_pool_gpu_shapes import _case
+errs, agree = _case(300, 3, 512, 8, torch.bfloat16, True, seed=11)
+print("RESULT " + json.dumps(dict(errs=errs, agree=agree)))
+"""
+
+
+@pytest.mark.parametrize("knobs", [{"AECF_NO_WS": "1"}, {"AECF_NO_GATE_FUSION": "1"}], ids=["tiled", "separate_gate"])
+def test_bf16_fallback_kernels_at_the_hot_path_shape(knobs):
+    """The kernels that serve shapes the weight-stationary engine does not take (tiled NT GEMM, per-modality value
+    projection, stand-alone gate, tiled dx) stay correct at d=512 / 8 heads / M=3: the library's A/B switches route the
+    hot-path shape through them in a child process (the switches are read once per process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    env = dict(os.environ, **knobs)
+    out = subprocess.run([sys.executable, "-c", _FALLBACK_SCRIPT.format(root=ROOT)], env=env, capture_output=True,
+                         text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    tol = 1e-3 + 2.0 ** -8
+    for k in ("y", "wbar", "dx"):
+        assert res["errs"][k] < tol, (k, res["errs"][k])
+    for k in ("dw_in", "db_in", "dw_out", "db_out"):
+        assert res["errs"][k] < 4e-3, (k, res["errs"][k])
+    assert res["errs"]["dq"] < 6e-3
+    assert res["agree"] > 0.99
