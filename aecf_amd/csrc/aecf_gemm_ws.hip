@@ -13,6 +13,9 @@
 // Modes:  PLAIN  C = A W^T + bias                                  (out-projection, dout = dy W_o)
 //         VPROJ  rows (b,m) of x:  V[b,m,:] = x[b,m,:] W_v^T + b_v (saved for the backward, optional) and
 //                o[b,n] = sum_m probs[b, head(n), m] V[b,m,n]
+//         VFLAT  the same result for M = 4 when 16 samples x M rows x K do not fit LDS twice (K = 768 / 1024): the
+//                (b,m) rows are walked as PLAIN rows (32 per step = 8 samples), a lane holds ONE (b,m) row, so its
+//                softmax weight is a per-lane scalar and o is a sum over the 4 lanes of a quad (two xor shuffles)
 // One barrier per step; LDS tile rows are K*2 bytes with the 16-byte chunk index XOR-ed with the MFMA column index
 // (bank-conflict-free ds_read_b128; the DMA destination is lane-linear, so the XOR is applied to the source address).
 #include "aecf_kernels.h"
@@ -22,7 +25,7 @@ namespace aecf {
 
 namespace {
 
-enum { WS_PLAIN = 0, WS_VPROJ = 1 };
+enum { WS_PLAIN = 0, WS_VPROJ = 1, WS_VFLAT = 2 };
 
 // copy NROWS rows (K bf16 each) to an LDS tile; row r's physical chunk p holds logical chunk p ^ key(r),
 // key(r) = (r / KEYDIV) & 15.  Rows >= rows_valid re-read the last valid row (their outputs are never stored).
@@ -74,9 +77,12 @@ template <int KT, int MODE, int M_, bool GATE, int CT>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
     constexpr int K = 32 * KT, ROWB = 2 * K;
-    constexpr int RT = MODE == WS_PLAIN ? 2 : M_;                 // 16-row MFMA tiles per step
+    constexpr bool PL = MODE != WS_VPROJ;                         // plain row tiles (PLAIN, VFLAT)
+    constexpr bool VF = MODE == WS_VFLAT;
+    constexpr int NPM = MODE == WS_VPROJ ? M_ : (VF ? 2 : 1);     // softmax weights a lane needs per step
+    constexpr int RT = PL ? 2 : M_;                 // 16-row MFMA tiles per step
     constexpr int SROWS = 16 * RT;                                // A rows per step
-    constexpr int OROWS = MODE == WS_PLAIN ? 32 : 16;             // output rows (PLAIN) / samples (VPROJ) per step
+    constexpr int OROWS = PL ? 32 : 16;             // output rows (PLAIN) / samples (VPROJ) per step
     constexpr int TILE = SROWS * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -90,18 +96,18 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     const int ncol0 = (int)group_u * BC + CW * w;                 // this wave's output columns
     // output rows (PLAIN) / samples (VPROJ) of this block
     const int64_t o_beg = (int64_t)chunk_u * rows_per_block;
-    const int64_t o_all = MODE == WS_PLAIN ? p.R : p.R;           // VPROJ: R counts samples
+    const int64_t o_all = p.R;                                    // rows (PLAIN, VFLAT: B*M of them) or samples (VPROJ)
     const int64_t o_end = (o_beg + rows_per_block) < o_all ? (o_beg + rows_per_block) : o_all;
     if (o_beg >= o_end) return;
 
     const char* asrc = reinterpret_cast<const char*>(p.a);
     // A rows: PLAIN row r of a [R, lda] matrix; VPROJ row (b, m) of x viewed as [B*M, K] (lda = M*K)
-    const unsigned int row_pitch = (MODE == WS_PLAIN ? (unsigned)p.lda : (unsigned)K) * 2u;
-    const int a_rows_per_o = MODE == WS_PLAIN ? 1 : M_;
+    const unsigned int row_pitch = (PL ? (unsigned)p.lda : (unsigned)K) * 2u;
+    const int a_rows_per_o = PL ? 1 : M_;
 
     auto issue = [&](int64_t o0, int buf) {                        // DMA of the step that starts at output row o0
         const int ov = (int)((o_end - o0) < OROWS ? (o_end - o0) : OROWS);
-        ws_dma_rows<KT, SROWS, (MODE == WS_PLAIN ? 1 : M_)>(asrc + o0 * a_rows_per_o * (int64_t)row_pitch, row_pitch,
+        ws_dma_rows<KT, SROWS, (PL ? 1 : M_)>(asrc + o0 * a_rows_per_o * (int64_t)row_pitch, row_pitch,
                                                             ov * a_rows_per_o, smem + buf * TILE);
     };
 
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     int xaddr[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-        xaddr[v] = (MODE == WS_PLAIN ? r16 : r16 * M_) * ROWB + ((((4 * v) + lg) ^ r16) << 4);
+        xaddr[v] = (PL ? r16 : r16 * M_) * ROWB + ((((4 * v) + lg) ^ r16) << 4);
 
     // Synchronisation: the DMA of step s+1 is issued right after the barrier of step s and retired by the
     // s_waitcnt vmcnt(0) that FOLLOWS the MFMAs of step s (a whole step of compute later: it also retires the
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     // VPROJ: this lane's sample, softmax weights of the wave's head, loaded ONE STEP AHEAD by inline asm (an ordinary
     // load beside an in-flight LDS-DMA makes hipcc wait vmcnt(0) in front of the first MFMA, which would serialise
     // the DMA with the compute); the end-of-step s_waitcnt vmcnt(0) retires them with the tile they belong to.
-    float pm[MODE == WS_VPROJ ? M_ : 1], pm_next[MODE == WS_VPROJ ? M_ : 1];
+    float pm[NPM], pm_next[NPM];
     // GATE: this wave's K-steps of the score product and its operands (rows of A hi/lo = heads), partial-sum buffer
     constexpr int KG = (KT + 7) / 8;
     float* gpart = reinterpret_cast<float*>(smem + 2 * TILE);     // [8 waves][M][16 heads][16 samples]
@@ -173,12 +179,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 #pragma unroll
             for (int m = 0; m < M_; ++m)
                 asm volatile("global_load_dword %0, %1, off" : "=v"(dst[m]) : "v"(pp + m) : "memory");
+        } else if (VF) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                         // this lane's two (b, m) rows of the step
+                const int64_t row = (o0 + 16 * t + r16) < o_end ? (o0 + 16 * t + r16) : (o_end - 1);
+                const int64_t b = row / M_;
+                const float* pp = p.probs + (b * H + head) * M_ + (row - b * M_);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(dst[t]) : "v"(pp) : "memory");
+            }
         }
     };
     load_probs(o_beg, pm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int m = 0; m < (MODE == WS_VPROJ ? M_ : 1); ++m) {
+    for (int m = 0; m < NPM; ++m) {
         if (GATE) { asm volatile("" : "+v"(kp_next[m])); kp[m] = p.g_kpm ? kp_next[m] : 0u; }
         else asm volatile("" : "+v"(pm[m]));
     }
@@ -241,12 +255,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
         constexpr int PF = 3;
         const char* tb = smem + cur * TILE;
         auto rd = [&](int i) -> u32x4 {
-            const int ks = MODE == WS_PLAIN ? i / RT : i % KT;
-            const int t = MODE == WS_PLAIN ? i % RT : i / KT;
-            const int toff = (MODE == WS_PLAIN ? 16 * t * ROWB : t * ROWB) + (ks >> 2) * 256;
+            const int ks = PL ? i / RT : i % KT;
+            const int t = PL ? i % RT : i / KT;
+            const int toff = (PL ? 16 * t * ROWB : t * ROWB) + (ks >> 2) * 256;
             return *reinterpret_cast<const u32x4*>(tb + xaddr[ks & 3] + toff);
         };
-        constexpr int NACC = MODE == WS_PLAIN ? RT : 1;
+        constexpr int NACC = PL ? RT : 1;
         f32x4 acc[NACC][CT];
 #pragma unroll
         for (int t = 0; t < NACC; ++t)
@@ -264,8 +278,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
-            const int ks = MODE == WS_PLAIN ? i / RT : i % KT;
-            const int t = MODE == WS_PLAIN ? i % RT : 0;
+            const int ks = PL ? i / RT : i % KT;
+            const int t = PL ? i % RT : 0;
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[t][c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[t][c]);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
@@ -288,8 +302,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
         }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tile (and its probabilities) landed
+        float pm_now[NPM];                                         // (the weights of THIS step: pm is refilled below)
 #pragma unroll
-        for (int m = 0; m < (MODE == WS_VPROJ ? M_ : 1); ++m) {
+        for (int m = 0; m < NPM; ++m) pm_now[m] = pm[m];
+#pragma unroll
+        for (int m = 0; m < NPM; ++m) {
             if (GATE) {
                 asm volatile("" : "+v"(kp_next[m]));
                 kp[m] = p.g_kpm ? kp_next[m] : 0u;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
             }
         }
         // ---- stores: lane (lg, r16) holds columns ncol0 + NV lg + 4 c + r (c < CT; r = 0..3) of row / sample r16
-        if (MODE == WS_PLAIN) {
+        if (PL) {
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 const int64_t row = o0 + 16 * t + r16;
@@ -308,7 +325,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
                 for (int c = 0; c < CT; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[t][c][r] + bias[4 * c + r];
-                if (row < o_end) store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + NV * lg, v);
+                if (!VF) {
+                    if (row < o_end) store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + NV * lg, v);
+                } else {
+                    if (p.v_out && row < o_end)
+                        store_cols<CT>(reinterpret_cast<unsigned short*>(p.v_out) + row * N + ncol0 + NV * lg, v);
+                    float ow[NV];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {                 // o = sum over the quad's 4 modality rows (M_ == 4)
+                        float a = pm_now[t] * v[j];
+                        a += __shfl_xor(a, 1, 64);
+                        a += __shfl_xor(a, 2, 64);
+                        ow[j] = a;
+                    }
+                    if ((r16 & 3) == 0 && row < o_end)
+                        store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + (row / M_) * N + ncol0 + NV * lg, ow);
+                }
             }
         } else {
             const int64_t b = o0 + r16;
@@ -573,8 +605,8 @@ template <int KT, int MODE, int M_, bool GATE>
 void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
     constexpr int CT = KT <= 16 ? 2 : 1;                           // 32 columns per wave up to K = 512, 16 beyond
-    constexpr int RT = MODE == WS_PLAIN ? 2 : M_;
-    constexpr int OROWS = MODE == WS_PLAIN ? 32 : 16;
+    constexpr int RT = MODE != WS_VPROJ ? 2 : M_;
+    constexpr int OROWS = MODE != WS_VPROJ ? 32 : 16;
     size_t smem = (size_t)2 * 16 * RT * 2 * K;
     const int groups = a.N / (128 * CT);
     // about one block per CU (256): chunks of whole steps
@@ -608,11 +640,18 @@ void launch_kt(const GemmNtArgs& a, hipStream_t s) {
 // shapes the weight-stationary kernel takes (bf16 only); everything else stays on the tiled kernels
 static bool ws_k_ok(int K) { return K == 128 || K == 256 || K == 384 || K == 512 || K == 768 || K == 1024; }
 
+// value projection with M = 4 whose per-sample tile (16 samples x 4 rows x K, twice) does not fit LDS: flat-row form
+static bool ws_vproj_flat(const GemmNtArgs& a) {
+    const size_t tile = (size_t)16 * a.M * 2 * a.K;
+    return (a.pooled & 1) && a.M == 4 && !a.g_ahi && 2 * tile > 150 * 1024 && (size_t)2 * 32 * 2 * a.K <= 150 * 1024;
+}
+
 bool gemm_ws_supported(const GemmNtArgs& a) {
     if (a.out_f32 || !ws_k_ok(a.K)) return false;
     const int ct = a.K <= 512 ? 2 : 1;
     if (a.N % (128 * ct) != 0) return false;
     const bool vproj = (a.pooled & 1) != 0;
+    if (vproj && ws_vproj_flat(a)) return a.hd % (16 * ct) == 0 && a.lda == (int64_t)a.M * a.K;
     const size_t tile = (size_t)16 * (vproj ? a.M : 2) * 2 * a.K;          // LDS: two tiles (+ the score partials)
     size_t smem = 2 * tile + (vproj && a.g_ahi ? (size_t)8 * a.M * 1024 : 0);
     if (smem > 150 * 1024) return false;
@@ -621,6 +660,13 @@ bool gemm_ws_supported(const GemmNtArgs& a) {
 }
 
 void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s) {
+    if (ws_vproj_flat(a)) {
+        GemmNtArgs f = a;                      // the (b, m) rows of x as B*M plain rows of K
+        f.R = a.R * a.M;
+        f.lda = a.K;
+        launch_kt<WS_VFLAT, 4, false>(f, s);
+        return;
+    }
     if (a.pooled & 1) {
         switch (a.M) {
             case 1: if (a.g_ahi) launch_kt<WS_VPROJ, 1, true>(a, s); else launch_kt<WS_VPROJ, 1, false>(a, s); break;
