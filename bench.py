@@ -267,6 +267,7 @@ def main():
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()                 # rank 0 is still measuring its stage times: leave together
         dist.destroy_process_group()
 
 
