@@ -347,7 +347,7 @@ int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, voi
     rs.src[1] = (const float*)(ws + L.cs_o);   rs.dst[1] = a->db_out;                              rs.n[1] = E;
     rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = (char*)a->dw_in + (size_t)2 * E * E * gsz; rs.n[2] = (int64_t)E * E;
     rs.src[3] = (const float*)(ws + L.cs_v);   rs.dst[3] = (char*)a->db_in + (size_t)2 * E * gsz;  rs.n[3] = E;
-    rs.src[4] = (const float*)(ws + L.u_slab); rs.dst[4] = u;                                      rs.n[4] = (int64_t)HPAD * E;
+    rs.src[4] = (const float*)(ws + L.u_slab); rs.dst[4] = u;                                      rs.n[4] = (int64_t)H * E;
     launch_reduce_segments(rs, s);
 
     FinalizeArgs f;

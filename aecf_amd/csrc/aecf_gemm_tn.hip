@@ -267,90 +267,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs p) {
     }
 }
 
-// u[split][h][k] = sum_{b in split} sum_m ds[b,h,m] x[b,m,k]  (key-side gradient; dW_k,h = qs_h (x) u[h]).
-// Same transposed staging as above for the raw x tiles (one LDS tile per modality); the A operand (rows =
-// heads) is built in registers from ds, as a bf16 hi/lo pair so the small ds values keep ~16 bits.
-// grid (ceil(E/128), 1, S); block 256: wave w owns column tiles 2w, 2w+1 of the 128 k columns.
-template <typename T, int M_>
-__global__ __launch_bounds__(256, 2) void gemm_tn_u_kernel(GemmTnArgs p) {
-    using X = Tr<T>;
-    typedef typename X::frag frag;
-    constexpr int NR = TBlk<T>::NR, NF = TBlk<T>::NF;
-    constexpr int BBT = TileK<T>::value;
-    constexpr int FG = 128 / NF;
-    extern __shared__ __attribute__((aligned(16))) char smem[];    // M_ tiles of [128][128 B]
-    const int E = p.E, H = p.H;
-    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
-    const int k0 = blockIdx.x * 128;
-    const int split = blockIdx.z;
-    const int64_t rbeg = (int64_t)split * p.u_rows_per_split;
-    const int64_t rend = (rbeg + p.u_rows_per_split) < p.B ? (rbeg + p.u_rows_per_split) : p.B;
-    const int kcols = (E - k0) >= 128 ? 128 : (E - k0);
-    const int fgr = threadIdx.x % FG, bgr = threadIdx.x / FG;
-    const bool r_on = NF * fgr < kcols;
-    const char* rhs = reinterpret_cast<const char*>(p.rhs);
-    const int64_t ldr = (int64_t)M_ * E * X::BYTES;
-    f32x4 uacc[2];
-    uacc[0] = uacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    TBlk<T> Rb[M_];
-    auto load_step = [&](int64_t base) {
-#pragma unroll
-        for (int m = 0; m < M_; ++m)
-#pragma unroll
-            for (int t = 0; t < NR; ++t) {
-                const int64_t bb = base + NR * bgr + t;
-                if (r_on && bb < rend) Rb[m].load_row(t, rhs + bb * ldr + ((int64_t)m * E + k0 + NF * fgr) * X::BYTES);
-                else Rb[m].zero_row(t);
-            }
-    };
-    load_step(rbeg);
-    for (int64_t base = rbeg; base < rend; base += BBT) {
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < M_; ++m) Rb[m].store_t(smem + m * 128 * TILE_ROW_BYTES, NF * fgr, bgr);
-        if (base + BBT < rend) load_step(base + BBT);
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < M_; ++m) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float dv[X::EPL], dl[X::EPL];
-#pragma unroll
-                for (int e = 0; e < X::EPL; ++e) {
-                    const int64_t bb = base + X::EPL * (4 * ks + lg) + e;
-                    dv[e] = (bb < rend && r16 < H) ? p.dsbuf[(bb * H + r16) * M_ + m] : 0.f;
-                }
-                frag dhi = X::pack(dv), dlo = dhi;
-                if (X::BYTES == 2) {
-                    float hv[X::EPL];
-                    X::unpack(dhi, hv);
-#pragma unroll
-                    for (int e = 0; e < X::EPL; ++e) dl[e] = dv[e] - hv[e];
-                    dlo = X::pack(dl);
-                }
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int col0 = 32 * w + 16 * c;
-                    if (col0 < kcols) {
-                        frag xb = lds_frag<T>(smem + m * 128 * TILE_ROW_BYTES, col0 + r16, 4 * ks + lg);
-                        uacc[c] = X::mma(dhi, xb, uacc[c]);
-                        if (X::BYTES == 2) uacc[c] = X::mma(dlo, xb, uacc[c]);
-                    }
-                }
-            }
-        }
-    }
-    float* u = p.u + (int64_t)split * HPAD * E;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int col0 = 32 * w + 16 * c;
-        if (col0 < kcols) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) u[(int64_t)(4 * lg + r) * E + k0 + col0 + r16] = uacc[c][r];
-        }
-    }
-}
-
 // u = ds^T x as a streaming kernel on the vector ALU (float32 exact): x is read ONCE, 16 bytes per lane; a wave owns a
 // 64-lane slice of the row (512 bf16 / 256 f32 columns) and keeps u[8 heads][its columns] in registers; the softmax-
 // gradient scalars ds[b, h, m] are wave-uniform (scalar loads).  8 waves per block walk the block's batch split, then
@@ -411,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void u_stream_kernel(GemmTnArgs p) {
         }
     }
     // fold the 8 waves' partials in wave order, 4 heads per pass
-    float* u = p.u + (int64_t)split * HPAD * E;
+    float* u = p.u + (int64_t)split * H * E;             // slab [split][H][E]: only the heads that exist
     constexpr int SL = 64 * CH;                         // columns of the slice
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -427,15 +343,7 @@ __global__ __launch_bounds__(512, 2) void u_stream_kernel(GemmTnArgs p) {
 #pragma unroll
             for (int ww = 0; ww < 8; ++ww) a += red[(ww * 4 + hh) * SL + cc];
             const int h = h0 + 4 * pass + hh, k = blockIdx.x * SL + cc;
-            if (h < HPAD && k < E) u[(int64_t)h * E + k] = h < H ? a : 0.f;
-        }
-    }
-    // rows H..HPAD-1 that no head group covers stay zero for the consumers
-    if (blockIdx.y == 0) {
-        const int covered = ((H + HG - 1) / HG) * HG;
-        for (int i = threadIdx.x; i < (HPAD - covered) * SL; i += 512) {
-            const int h = covered + i / SL, k = blockIdx.x * SL + i % SL;
-            if (h < HPAD && k < E) u[(int64_t)h * E + k] = 0.f;
+            if (h < H && k < E) u[(int64_t)h * E + k] = a;
         }
     }
 }
