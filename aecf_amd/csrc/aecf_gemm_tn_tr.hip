@@ -14,8 +14,10 @@
 //     2048 (r >> 3) + 512 (ch >> 2) + 64 (r & 7) + 16 ((ch & 3) ^ ((r >> 2) & 3))
 // (cdna_hip_programming.md T10, image (a)): the DMA writes, the b128 writes and the transposed reads are bank-conflict
 // free, and all 24 transposed reads of a wave's step share 4 address registers (the rest are immediates).
-// Block = 512 threads (8 waves as 4 (j) x 2 (k)), block tile 128 x 128, wave tile 32 x 64, 64 batch rows per step.
+// Block = 512 threads (8 waves as 4 (j) x 2 (k)), block tile 128 x 128, wave tile 32 x 64, 64 batch rows per step;
+// the pooled product also has a 1024-thread form with a 256 x 128 tile (gemm_tn_tr_wide_kernel below), used when it fits.
 // Output: float32 partial slabs per batch split (deterministic; reduced by reduce_segments).
+#include <stdlib.h>
 #include "aecf_kernels.h"
 #include "aecf_tile.h"
 
@@ -327,6 +329,264 @@ __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(Gemm
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// WIDE pooled variant: 1024 threads = 16 waves as 8 (j) x 2 (k), block tile 256 (j) x 128 (k), ONE block per CU.
+// The same pooled x slice now serves 4 head slots instead of 2: the bf16 unpack of x and the per-step address work are
+// spent once per 256 output rows (half the vector instructions per output), x crosses L2 -> LDS twice instead of four
+// times, and the wave count per CU is unchanged (16).  A thread pools ONE 16-byte chunk of a row (64 rows x 16 chunks).
+// lhs tile = two 128-wide sub-tiles of the [64][128] image, double buffered (64 KB); rhs = MAXS pooled tiles.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma_subtile_1024(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid,
+                                                 int chunks_valid, char* lds) {
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    const int c = threadIdx.x;                                    // 1024 chunks = one [64][128] image
+    const int row = 8 * (c >> 7) + ((c >> 2) & 7);
+    const int rowc = row < rows_valid ? row : rows_valid - 1;
+    int logical = 4 * ((c >> 5) & 3) + ((c & 3) ^ ((row >> 2) & 3));
+    logical = logical < chunks_valid ? logical : 0;
+    const unsigned int voff = (unsigned)rowc * ld_bytes + (unsigned)logical * 16u;
+    const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(lds + wbase * 16);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(src), "s"(dst) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+template <int M_, int MAXS>
+__global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) {
+    using X = Tr<BF16>;
+    constexpr int RT = 2, CT = 4;
+    constexpr int PLN = (TRB * MAXS * M_ + 1023) / 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int E = p.E, H = p.H;
+    const int EJ = p.Ej > 0 ? p.Ej : p.E;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+
+    const unsigned int nK = (unsigned)((E + 127) / 128), nJt = (unsigned)((EJ + 255) / 256);
+    unsigned int split_u, tile_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)p.splits, nK * nJt, split_u, tile_u)) return;
+    const int kt_idx = (int)(tile_u % nK), jt_idx = (int)(tile_u / nK);
+    const int j0 = jt_idx * 256, k0 = kt_idx * 128;
+    const int split = (int)split_u;
+    const int64_t rbeg = (int64_t)split * p.rows_per_split;
+    const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
+    const int jrows = (EJ - j0) >= 256 ? 256 : (EJ - j0);     // multiples of 64
+    const int kcols = (E - k0) >= 128 ? 128 : (E - k0);
+
+    const int h_first = j0 / p.hd;
+    const int h_last = (j0 + jrows - 1) / p.hd;
+    const int nslots = h_last - h_first + 1;
+
+    // LDS carve: lhs [2 buffers][2 sub-tiles] | MAXS pooled rhs tiles | probabilities
+    char* ldsL = smem;
+    char* ldsR = smem + 4 * TR_TILE;
+    f32x2* pl = reinterpret_cast<f32x2*>(ldsR + MAXS * TR_TILE);       // [TRB][MAXS][M] (p, p) pairs
+
+    // wave tile 32 (j) x 64 (k)
+    const int j0w = 32 * (w >> 1), k0w = 64 * (w & 1);
+    const bool wave_on = j0w < jrows && k0w < kcols;
+    const int wslot = (j0 + (j0w < jrows ? j0w : 0)) / p.hd - h_first;
+    const bool do_cs = p.colsum != nullptr && kt_idx == 0 && k0w == 0;
+
+    const int q = r16 >> 2, pp = r16 & 3;
+    int tx[2][2];
+#pragma unroll
+    for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            tx[b1][hh] = 2048 * lg + 64 * q + 8 * (pp & 1) + 256 * hh + 16 * ((2 * b1 + (pp >> 1)) ^ (2 * (lg & 1) + hh));
+    const int a_org = (j0w >> 7) * TR_TILE + 512 * ((w >> 1) & 3);   // sub-tile, then lhs block 2 ((w >> 1) & 3) + rt
+    const int b_org = 1024 * (w & 1);
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 csacc[RT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) csacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* lhs = reinterpret_cast<const char*>(p.lhs);
+    const char* rhs = reinterpret_cast<const char*>(p.rhs);
+    const unsigned int ldl = (unsigned)EJ * 2u;
+    const unsigned int ldr = (unsigned)M_ * (unsigned)E * 2u;
+
+    // pooling role of this thread: batch row prow, 16-byte chunk pc of the 128-feature slice
+    const int prow = threadIdx.x >> 4, pc = threadIdx.x & 15;
+    const unsigned int prow_off = (unsigned)prow * ldr;
+    const unsigned int coff = 8 * pc < kcols ? 16u * pc : 0u;
+    u32x4 Rb[M_];
+    float plr[PLN];
+
+    auto issue_dma = [&](int64_t base, int buf) {
+        const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        const char* src = lhs + base * (int64_t)ldl + (int64_t)j0 * 2;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+            if (128 * sub < jrows)                        // (block-uniform)
+                dma_subtile_1024(src + 256 * sub, ldl, nvalid, (jrows - 128 * sub) >= 128 ? 16 : (jrows - 128 * sub) >> 3,
+                                 ldsL + (2 * buf + sub) * TR_TILE);
+    };
+    auto probs_on = [&](int64_t base, int i) -> bool {
+        const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        const int idx = threadIdx.x + 1024 * i;
+        const int t = idx / (MAXS * M_), rem = idx - t * (MAXS * M_);
+        return idx < TRB * MAXS * M_ && rem / M_ < nslots && t < nvalid;
+    };
+    auto load_probs = [&](int64_t base) {
+        const float* pu = p.probs + (base * H + h_first) * M_;
+#pragma unroll
+        for (int i = 0; i < PLN; ++i) {
+            const int idx = threadIdx.x + 1024 * i;             // (t, s, m) with MAXS slots per row
+            const int t = idx / (MAXS * M_), rem = idx - t * (MAXS * M_);
+            const int sl = rem / M_, m = rem - sl * M_;
+            const float* src = pu + (probs_on(base, i) ? (unsigned)(t * H * M_ + sl * M_ + m) : 0u);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(plr[i]) : "v"(src) : "memory");
+        }
+    };
+    auto load_x = [&](int64_t base) {
+        const int nvalid = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        const char* xu = rhs + base * (int64_t)ldr + (int64_t)k0 * 2;
+        const unsigned int last = (unsigned)(nvalid - 1) * ldr;
+        const unsigned int roff = (prow_off < last ? prow_off : last) + coff;
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            const char* xm = xu + (size_t)m * E * 2;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(Rb[m]) : "v"(roff), "s"(xm) : "memory");
+        }
+    };
+    auto mma_phase = [&](int cur, int nvalid_cur) {
+        if (wave_on) {
+            const char* lt = ldsL + 2 * cur * TR_TILE;
+            const char* rt_tile = ldsR + wslot * TR_TILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    a[rt] = tr_frag(lt + a_org + 8192 * ks, tx[rt][0], tx[rt][1]);
+                if (do_cs) {
+                    u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                    if (nvalid_cur < TRB) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const int kk = 32 * ks + 8 * lg + 2 * d;
+                            ones[d] = (kk < nvalid_cur ? 0x3f80u : 0u) | (kk + 1 < nvalid_cur ? 0x3f800000u : 0u);
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) csacc[rt] = X::mma(a[rt], ones, csacc[rt]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const u32x4 b = tr_frag(rt_tile + b_org + 8192 * ks + 512 * (ct >> 1), tx[ct & 1][0], tx[ct & 1][1]);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = X::mma(a[rt], b, acc[rt][ct]);
+                }
+            }
+        }
+    };
+
+    // One step: the lhs DMA, the probabilities and the x chunk of step k+1 are issued during step k and retired by the
+    // wait at the top of step k+1.  (Fetching x two steps ahead -- a second chunk register set, counted vmcnt -- was
+    // measured neutral: per step the vector phase, the LDS/MFMA phase and the barriers add up; nothing waits on memory.)
+    auto do_step = [&](int64_t base, int cur) {
+        const bool more1 = base + TRB < rend;
+        const int nvalid_cur = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < PLN; ++i) {
+            asm volatile("" : "+v"(plr[i]));
+            const int idx = threadIdx.x + 1024 * i;
+            const float pv = probs_on(base, i) ? plr[i] : 0.f;
+            if (idx < TRB * MAXS * M_) pl[idx] = f32x2{pv, pv};
+        }
+#pragma unroll
+        for (int m = 0; m < M_; ++m) asm volatile("" : "+v"(Rb[m]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // MFMAs of the previous step done; lhs tile + probabilities visible
+        if (more1) {
+            issue_dma(base + TRB, cur ^ 1);
+            load_probs(base + TRB);
+        }
+        const f32x2* plc = pl + prow * (MAXS * M_);
+        f32x2 xv[M_][4];
+#pragma unroll
+        for (int m = 0; m < M_; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xv[m][i] = f32x2{__uint_as_float(Rb[m][i] << 16), __uint_as_float(Rb[m][i] & 0xffff0000u)};
+#pragma unroll
+        for (int m = 0; m < M_; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[m][i]));
+        if (more1) load_x(base + TRB);                    // the chunk registers are free again: next step's chunk flies
+        const int woff = tr_off(prow, pc);
+#pragma unroll
+        for (int sl = 0; sl < MAXS; ++sl) {
+            if (sl < nslots) {
+                f32x2 pv[4];
+                const f32x2 p0 = plc[sl * M_];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pv[i] = xv[0][i] * p0;
+#pragma unroll
+                for (int m = 1; m < M_; ++m) {
+                    const f32x2 pm = plc[sl * M_ + m];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pv[i] = __builtin_elementwise_fma(xv[m][i], pm, pv[i]);
+                }
+                u32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // pooled tiles visible
+        mma_phase(cur, nvalid_cur);
+    };
+
+    if (rbeg < rend) {
+        issue_dma(rbeg, 0);
+        load_probs(rbeg);
+        load_x(rbeg);
+    }
+    int cur = 0;
+    for (int64_t base = rbeg; base < rend; base += TRB, cur ^= 1) do_step(base, cur);
+
+    float* out = p.out + (int64_t)split * EJ * E;
+    if (wave_on) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (k0w + 16 * ct < kcols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        out[(int64_t)(j0 + j0w + 16 * rt + 4 * lg + r) * E + k0 + k0w + 16 * ct + r16] = acc[rt][ct][r];
+                }
+        if (do_cs && r16 == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    p.colsum[(int64_t)split * EJ + j0 + j0w + 16 * rt + 4 * lg + r] = csacc[rt][r];
+        }
+    }
+}
+
+template <int M_, int MAXS>
+void launch_wide(const GemmTnArgs& a, hipStream_t s) {
+    size_t smem = (size_t)(4 + MAXS) * TR_TILE + (size_t)TRB * MAXS * M_ * 2 * sizeof(float);
+    const int EJ = a.Ej > 0 ? a.Ej : a.E;
+    dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)(((a.E + 127) / 128) * ((EJ + 255) / 256)))), block(1024);
+    auto kern = gemm_tn_tr_wide_kernel<M_, MAXS>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a);
+}
+
 template <int M_, bool POOLED, int MAXS>
 void launch_one(const GemmTnArgs& a, hipStream_t s) {
     size_t smem = (size_t)2 * TR_TILE + (size_t)(POOLED ? MAXS : 2) * TR_TILE;
@@ -353,8 +613,29 @@ static int max_slots_128(int E, int hd) {
 }
 
 // bf16 only; head_dim % 32 == 0 (a wave's 32 output rows lie inside one head)
+// head slots of the widest aligned 256-row window
+static int max_slots_256(int E, int hd) {
+    int mx = 1;
+    for (int j0 = 0; j0 < E; j0 += 256) {
+        const int j1 = (j0 + 256 < E ? j0 + 256 : E) - 1;
+        const int n = j1 / hd - j0 / hd + 1;
+        if (n > mx) mx = n;
+    }
+    return mx;
+}
+
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s) {
     if (!a.pooled) { launch_one<1, false, 1>(a, s); return; }
+    // 256-row tiles (1024 threads) when they tile E exactly with at most 4 head slots and M <= 3 (128-VGPR budget)
+    static const int no_wide = getenv("AECF_NO_WIDE_TN") ? atoi(getenv("AECF_NO_WIDE_TN")) : 0;      // A/B timing only
+    if (!no_wide && a.Ej <= 0 && a.E % 256 == 0 && a.M <= 3 && max_slots_256(a.E, a.hd) <= 4) {
+        const bool two = max_slots_256(a.E, a.hd) <= 2;
+        switch (a.M) {
+            case 1: if (two) launch_wide<1, 2>(a, s); else launch_wide<1, 4>(a, s); return;
+            case 2: if (two) launch_wide<2, 2>(a, s); else launch_wide<2, 4>(a, s); return;
+            default: if (two) launch_wide<3, 2>(a, s); else launch_wide<3, 4>(a, s); return;
+        }
+    }
     const int ns = max_slots_128(a.E, a.hd);
     AECF_DISPATCH_M(a.M, {
         if (ns <= 2) launch_one<M_, true, 2>(a, s);
