@@ -10,7 +10,7 @@ STAGE = [  # (regex on the kernel name, stage)
     (r"gemm_tn_tr_kernel<1, false", "bwd.dw_out"),
     (r"dscore_v_kernel", "bwd.dscore"),
     (r"dx_ws2?_kernel", "bwd.dx"), (r"bwd_g_kernel", "bwd.dx"),
-    (r"gemm_tn_tr_kernel<\d+, true", "bwd.dw_v"), (r"gemm_tn_u_kernel|u_stream_kernel", "bwd.u"), (r"gemm_tn_kernel", "bwd.dw_v"),
+    (r"gemm_tn_tr_kernel<\d+, true", "bwd.dw_v"), (r"gemm_tn_tr_wide_kernel", "bwd.dw_v"), (r"gemm_tn_u_kernel|u_stream_kernel", "bwd.u"), (r"gemm_tn_kernel", "bwd.dw_v"),
     (r"reduce_segments_kernel|fin_outer_kernel|fin_dquery_kernel", "bwd.finalize"),
     (r"prep_all_kernel", "prep"),
 ]
