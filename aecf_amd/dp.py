@@ -89,6 +89,9 @@ class FlatGradBucket:
         return works
 
 
+_avg_ok = True          # ReduceOp.AVG accepted by the backend (checked on first use)
+
+
 def flat_grad_alias(params: Iterable[torch.nn.Parameter]) -> Optional[torch.Tensor]:
     """The fusion layer's backward writes its five parameter gradients into ONE allocation (aecf_amd/layer.py:
     _PoolFunction.backward) and autograd keeps those tensors as ``p.grad`` without copying.  If the gradients of
@@ -123,12 +126,18 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
     copied = flat is None
     if copied:
         flat = torch.cat([p.grad.reshape(-1).to(params[0].grad.dtype) for p in params])
-    if average and dist.get_backend(group) == "nccl":
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    global _avg_ok
+    done = False
+    if average and _avg_ok and dist.get_backend(group) == "nccl":
+        try:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+            done = True
+        except (RuntimeError, ValueError):            # a backend build without AVG for this dtype: sum, then divide
+            _avg_ok = False
+    if not done:
         if average:
-            flat.div_(world)
+            flat.div_(world)                          # pre-divide: the sum of bf16 values then stays in range
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if copied:
         off = 0
         for p in params:
