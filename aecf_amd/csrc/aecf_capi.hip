@@ -551,6 +551,36 @@ int aecf_modality_frontend(int64_t rows, int32_t dim, int32_t dtype, const void*
     return launch_status();
 }
 
+int aecf_route_build(int64_t rows, const uint8_t* present_a, const uint8_t* present_b, int32_t* route, int32_t* slot,
+                     int32_t* index, int32_t* counts, void* stream) {
+    if (rows <= 0 || rows > 0x7fffffff) return AECF_ERR_BAD_DIMS;
+    if (!present_a || !present_b || !route || !slot || !index || !counts) return AECF_ERR_NULL_POINTER;
+    launch_route_build(rows, present_a, present_b, route, slot, index, counts, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_rows_gather(int32_t njobs, const void* const* src, const int64_t* src_pitch, const int32_t* const* index,
+                     const int64_t* n, void* const* dst, const int64_t* dst_pitch, int64_t row_bytes, void* stream) {
+    if (njobs < 1 || njobs > 3 || row_bytes <= 0 || row_bytes % 2 != 0) return AECF_ERR_BAD_DIMS;
+    if (!src || !src_pitch || !index || !n || !dst || !dst_pitch) return AECF_ERR_NULL_POINTER;
+    for (int k = 0; k < njobs; ++k) {
+        if (n[k] < 0 || src_pitch[k] % 2 != 0 || dst_pitch[k] % 2 != 0) return AECF_ERR_BAD_DIMS;
+        if (n[k] > 0 && (!src[k] || !index[k] || !dst[k])) return AECF_ERR_NULL_POINTER;
+    }
+    launch_rows_gather(njobs, src, src_pitch, index, n, dst, dst_pitch, row_bytes, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_rows_select(int64_t rows, int64_t row_bytes, const int32_t* route, const int32_t* slot, const void* const* src,
+                     const int64_t* src_pitch, void* dst, int64_t dst_pitch, void* stream) {
+    if (rows <= 0 || row_bytes <= 0 || row_bytes % 2 != 0 || dst_pitch % 2 != 0) return AECF_ERR_BAD_DIMS;
+    if (!route || !slot || !src || !src_pitch || !dst) return AECF_ERR_NULL_POINTER;
+    for (int k = 0; k < 3; ++k)
+        if (src_pitch[k] % 2 != 0) return AECF_ERR_BAD_DIMS;
+    launch_rows_select(rows, row_bytes, route, slot, src, src_pitch, dst, dst_pitch, (hipStream_t)stream);
+    return launch_status();
+}
+
 int aecf_l2norm_forward(int64_t n, int32_t d, int32_t dtype, float eps, const void* z, void* zn, float* inv_norm,
                         void* stream) {
     if (n <= 0 || d <= 0) return AECF_ERR_BAD_DIMS;

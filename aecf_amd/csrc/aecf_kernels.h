@@ -191,4 +191,12 @@ void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat
                               uint8_t* present, hipStream_t s);
 void launch_transpose_rect(int dtype, const void* src, void* dst, int64_t R, int64_t C, hipStream_t s);
 
+// ---------------- presence routing (aecf_route.hip) ----------------
+void launch_route_build(int64_t rows, const uint8_t* pa, const uint8_t* pb, int32_t* route, int32_t* slot, int32_t* index,
+                        int32_t* counts, hipStream_t s);
+void launch_rows_gather(int njobs, const void* const* src, const int64_t* src_pitch, const int32_t* const* index,
+                        const int64_t* n, void* const* dst, const int64_t* dst_pitch, int64_t row_bytes, hipStream_t s);
+void launch_rows_select(int64_t rows, int64_t row_bytes, const int32_t* route, const int32_t* slot, const void* const* src,
+                        const int64_t* src_pitch, void* dst, int64_t dst_pitch, hipStream_t s);
+
 }  // namespace aecf

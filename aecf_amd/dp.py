@@ -10,7 +10,11 @@ counterpart; it is what BASELINE.json's north_star asks for around the fused ker
   the 4E^2+5E values travel as a single collective (a few MB: latency-bound on xGMI, so one big
   message, not one per tensor), (2) an all-gather of fused embeddings for cross-batch contrastive
   negatives whose backward is a reduce-scatter of the gradient, (3) scalar means of the logged statistics.
-* mask RNG: every rank slices the SAME global uniform tensor, so N-rank masks equal 1-rank masks bit for bit.
+* mask RNG: every rank slices the SAME global uniform tensor (``global_uniforms`` + ``shard_batch``) and hands its rows
+  to the pool through the public ``uniforms=`` argument of ``MultimodalAttentionPool.forward`` /
+  ``CurriculumMasking.forward``, so N-rank masks equal 1-rank masks bit for bit.
+* replicas are made identical by ``broadcast_parameters``; gradient averaging is unweighted, uneven shards scale their
+  local loss by ``shard_loss_scale``.
 """
 from __future__ import annotations
 
@@ -89,7 +93,62 @@ class FlatGradBucket:
         return works
 
 
-_avg_ok = True          # ReduceOp.AVG accepted by the backend (checked on first use)
+# ReduceOp.AVG support of the backend, decided ONCE per (backend, dtype) by probe_avg_support -- a tiny all-reduce whose
+# outcome all ranks agree on -- never by catching an exception inside the step (RCCL errors surface asynchronously; ranks
+# that disagreed would issue different collectives and hang).  Unprobed = sum + divide, which every backend takes.
+_avg_support = {}
+
+
+def probe_avg_support(dtype: torch.dtype, device, group=None) -> bool:
+    """Collective: every rank calls it with the same arguments (at start-up).  Tries ReduceOp.AVG on 1 element, then
+    agrees on the outcome with a MIN all-reduce, so either all ranks use AVG from now on or none does."""
+    _, world = world_info(group)
+    key = (dist.get_backend(group) if world > 1 else "none", dtype)
+    if key in _avg_support:
+        return _avg_support[key]
+    ok = 0
+    if world > 1 and key[0] == "nccl":
+        try:
+            t = torch.ones(1, dtype=dtype, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            ok = 1 if abs(float(t.item()) - 1.0) < 1e-3 else 0
+        except (RuntimeError, ValueError):
+            ok = 0
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item())
+    _avg_support[key] = bool(ok)
+    return bool(ok)
+
+
+def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=None) -> None:
+    """Replicas start identical: every parameter (and buffer) of rank ``src`` overwrites the other ranks' (one flat
+    broadcast per dtype).  Without it, replicas built under different RNG states would silently diverge."""
+    _, world = world_info(group)
+    if world == 1:
+        return
+    by_dtype = {}
+    for p in params:
+        by_dtype.setdefault(p.dtype, []).append(p)
+    with torch.no_grad():
+        for ps in by_dtype.values():
+            flat = torch.cat([p.detach().reshape(-1) for p in ps])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for p in ps:
+                p.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+
+
+def shard_loss_scale(b_local: int, b_global: int, world: int) -> float:
+    """Factor for a rank's mean-over-its-shard loss so that the AVERAGE of the ranks' gradients equals the gradient of
+    the mean loss over the global batch: ``world * b_local / b_global`` (1.0 for even shards).  shard_bounds hands the
+    first ranks one extra row when world does not divide the batch; all_reduce_grads / FlatGradBucket average without
+    weights, so uneven shards need this factor on the local loss (or an upstream gradient scaled by it)."""
+    return float(world) * float(b_local) / float(b_global)
 
 
 def flat_grad_alias(params: Iterable[torch.nn.Parameter]) -> Optional[torch.Tensor]:
@@ -116,8 +175,9 @@ def flat_grad_alias(params: Iterable[torch.nn.Parameter]) -> Optional[torch.Tens
 
 def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = True):
     """One collective for the gradients of ``params``: in place over their shared allocation when they alias one
-    (see flat_grad_alias), else through a temporary flat copy.  RCCL averages inside the collective (ReduceOp.AVG);
-    gloo sums and the division follows."""
+    (see flat_grad_alias), else through a temporary flat copy.  Averages inside the collective (ReduceOp.AVG) when
+    probe_avg_support found the backend takes it, else divides and sums.  The average is unweighted: with uneven
+    shards scale the local loss by shard_loss_scale."""
     params = [p for p in params if p.requires_grad and p.grad is not None]
     _, world = world_info(group)
     if world == 1 or not params:
@@ -126,15 +186,9 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
     copied = flat is None
     if copied:
         flat = torch.cat([p.grad.reshape(-1).to(params[0].grad.dtype) for p in params])
-    global _avg_ok
-    done = False
-    if average and _avg_ok and dist.get_backend(group) == "nccl":
-        try:
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
-            done = True
-        except (RuntimeError, ValueError):            # a backend build without AVG for this dtype: sum, then divide
-            _avg_ok = False
-    if not done:
+    if average and _avg_support.get((dist.get_backend(group), flat.dtype), False):
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
         if average:
             flat.div_(world)                          # pre-divide: the sum of bf16 values then stays in range
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

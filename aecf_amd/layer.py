@@ -39,18 +39,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-# Test hook: parity tests need the mask drawn from the SAME uniforms the CPU oracle consumed.  When set
-# to a tensor, the next forward uses it instead of torch.rand (and clears it).  Never set in production.
-_uniforms_override: Optional[torch.Tensor] = None
+def _draw_uniforms(shape, device, uniforms: Optional[torch.Tensor] = None,
+                   generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """The float32 uniforms of the Bernoulli draw (ref :204), one per weight element, row-major.
 
-
-def _draw_uniforms(shape, device) -> torch.Tensor:
-    global _uniforms_override
-    if _uniforms_override is not None:
-        u = _uniforms_override.to(device=device, dtype=torch.float32).reshape(shape).contiguous()
-        _uniforms_override = None
-        return u
-    return torch.rand(shape, dtype=torch.float32, device=device)
+    ``uniforms`` given: used as they are (any shape with the right element count) -- this is how a data-parallel
+    step feeds every rank ITS rows of one global tensor (``dp.global_uniforms`` + ``dp.shard_batch``) so that the
+    N-rank masks equal the 1-rank masks bit for bit, and how a caller replays a recorded draw.  Otherwise they are
+    drawn from ``generator`` (default: the device's default generator, which then advances by exactly
+    ``numel`` draws as ``torch.bernoulli`` would)."""
+    if uniforms is not None:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if uniforms.numel() != n:
+            raise ValueError(f"uniforms has {uniforms.numel()} elements, the mask needs {n} (shape {tuple(shape)})")
+        return uniforms.detach().to(device=device, dtype=torch.float32).reshape(shape).contiguous()
+    return torch.rand(shape, dtype=torch.float32, device=device, generator=generator)
 
 
 def _require_device(t: torch.Tensor, what: str) -> None:
@@ -386,8 +391,10 @@ class CurriculumMasking(nn.Module):
                                             float(self.entropy_target), 1e-8)
         return entropy.to(weights.dtype)
 
-    def forward(self, weights: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-        """ref :130-283."""
+    def forward(self, weights: torch.Tensor, *, uniforms: Optional[torch.Tensor] = None,
+                generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """ref :130-283.  ``uniforms`` / ``generator`` (keyword-only, not in the reference): where the Bernoulli
+        draw of ref :204 takes its float32 uniforms from -- see ``_draw_uniforms``."""
         _require_device(weights, "weights")
         dt = weights.dtype
         seq_len = weights.size(-1)
@@ -398,7 +405,7 @@ class CurriculumMasking(nn.Module):
         if seq_len <= 1:                                                      # ref :160-167
             z = torch.zeros(weights.shape[:-1], device=weights.device, dtype=dt)
             return weights, {'entropy': z, 'mask_rate': z.clone(), 'target_entropy': z.clone()}
-        uniforms = _draw_uniforms(tuple(weights.shape), weights.device)                      # ref :204
+        uniforms = _draw_uniforms(tuple(weights.shape), weights.device, uniforms, generator)   # ref :204
         masked, entropy, mask_rate = _MaskFunction.apply(weights, uniforms, 1, self.min_active,
                                                          float(self.base_mask_prob), float(self.entropy_target), 1e-8)
         self._last_seq_len = seq_len                                          # ref :187
@@ -472,8 +479,12 @@ class MultimodalAttentionPool(nn.Module):
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: Optional[torch.Tensor] = None,
                 key_padding_mask: Optional[torch.Tensor] = None, attn_mask: Optional[torch.Tensor] = None,
-                return_info: bool = False, use_checkpoint: bool = False,
+                return_info: bool = False, use_checkpoint: bool = False, *,
+                uniforms: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, Dict[str, Any]]]:
+        # ``uniforms`` / ``generator`` (keyword-only, not in the reference): source of the curriculum mask's float32
+        # uniforms, [B, tgt_len, src_len] (see _draw_uniforms; data-parallel callers pass their shard of
+        # dp.global_uniforms).  Ignored when no training-mode curriculum masking runs.
         # type / shape validation: ref :450-498 (messages identical)
         if not isinstance(query, torch.Tensor):
             raise TypeError(f"Expected query to be torch.Tensor, got {type(query)}")
@@ -537,10 +548,13 @@ class MultimodalAttentionPool(nn.Module):
         fast_ok = _lib.load().aecf_pool_check(ctypes.byref(_lib.PoolDesc(
             batch_size, src_len, embed_dim, self.num_heads, _DTYPES[key.dtype], 0, 1, 0.15, 0.7, 1e-8))) == 0
         general_ok = src_len <= 64 and tgt_len <= 64 and embed_dim % 64 == 0 and embed_dim <= 1024
-        if q_base is None or not same_kv or attn_mask is not None or dropping or (not fast_ok and general_ok):
+        float_kpm = key_padding_mask is not None and key_padding_mask.is_floating_point()   # additive in torch
+        if (q_base is None or not same_kv or attn_mask is not None or dropping or float_kpm
+                or (not fast_ok and general_ok)):
             # everything outside the shared-query hot path: the general attention kernels
             return self._forward_general(q_bf, x, value if self.batch_first else value.transpose(0, 1),
-                                         key_padding_mask, attn_mask, return_info, batch_size, tgt_len, src_len)
+                                         key_padding_mask, attn_mask, return_info, batch_size, tgt_len, src_len,
+                                         uniforms, generator)
         kpm = None
         if key_padding_mask is not None:
             if key_padding_mask.shape != (batch_size, src_len):
@@ -549,18 +563,18 @@ class MultimodalAttentionPool(nn.Module):
 
         cm = self.curriculum_masking
         mask_mode = 0
-        uniforms = None
+        mask_u = None
         if cm is not None:
             mask_mode = 1 if cm.training else 2
             if mask_mode == 1 and src_len <= 1:
                 mask_mode = 0          # ref :160-167 early-out: handled on the host below
             if mask_mode == 1:
                 # one float32 uniform per weight element, row-major, default generator (ref :204)
-                uniforms = _draw_uniforms((batch_size, tgt_len, src_len), x.device)
+                mask_u = _draw_uniforms((batch_size, tgt_len, src_len), x.device, uniforms, generator)
         a = self.attention
         tgt_value = math.log(float(src_len)) * cm.entropy_target if mask_mode == 1 else None        # ref :273
         y, attn_w, masked_w, entropy, mask_rate, tgt_entropy = _PoolFunction.apply(
-            x, q_base, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, kpm, uniforms,
+            x, q_base, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, kpm, mask_u,
             self.num_heads, mask_mode, 1 if cm is None else int(cm.min_active),
             0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8,
             False, tgt_value)
@@ -623,7 +637,7 @@ class MultimodalAttentionPool(nn.Module):
         return (attn_output, info) if return_info else attn_output
 
     def _forward_general(self, q_bf, k_bf, v_bf, key_padding_mask, attn_mask, return_info, batch_size, tgt_len,
-                         src_len):
+                         src_len, uniforms=None, generator=None):
         """nn.MultiheadAttention semantics for per-sample queries / tgt_len > 1 / key != value / attn_mask / dropout
         (ref :503-521 -> torch functional.py:5836-5852, 6504-6612), then the curriculum hook exactly as the
         reference applies it to the pooled weights (ref :526-541)."""
@@ -671,7 +685,7 @@ class MultimodalAttentionPool(nn.Module):
         info: Dict[str, Any] = {}
         cm = self.curriculum_masking
         if cm is not None:                                                     # ref :526-541
-            masked_weights, mask_info = cm(attn_weights)
+            masked_weights, mask_info = cm(attn_weights, uniforms=uniforms, generator=generator)
             info.update(mask_info)
             info['attention_weights'] = attn_weights
             if return_info:

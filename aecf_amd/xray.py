@@ -1,15 +1,19 @@
-"""Counterpart of the reference's only end-to-end caller of the fusion path:
-``AECFModel`` of ``xrays/train_xrays_example.py:108-237`` and one optimisation step of
-``train_both_models`` (``:312-377``), with the fusion done by the HIP path.
+"""The fusion path's only end-to-end caller in the reference, rebuilt around device-side routing
+(behaviour of ``AECFModel`` in ``xrays/train_xrays_example.py:108-237`` and of one
+optimisation step of ``train_both_models``, ``:360-377``).
 
-Encoders / projections / classifier are plain ``torch.nn.Linear`` layers exactly as in the reference (they are
-outside the hot path); presence routing, the gather of both-present rows into the pool and the scatter of the
-fused rows are the glue either side of the kernel.  Construction order (hence parameter initialisation under a
-seed and state_dict keys) is the reference's.
+What is kept from the reference: the module/attribute names and construction order (so a reference state_dict loads and a
+seeded construction draws the same parameters) and the forward contract ``model(images, texts, return_info) -> logits
+[, info]``.  What is different is how rows travel.  The reference masks, ``torch.where``-s, stacks and index-assigns
+three row subsets (six host synchronisations per step).  Here one routing table is built on the device from the presence
+bits (``aecf_route_build``), its four class sizes are the single value read back, and rows move through two kernels:
+``aecf_rows_gather`` (compact the rows a branch needs) and ``aecf_rows_select`` (write every fused row exactly once from the
+branch that owns it, zeros for rows with no modality).  Each is the other's backward.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+import ctypes
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
@@ -17,15 +21,20 @@ import torch.nn as nn
 from .layer import CurriculumMasking, MultimodalAttentionPool, _DTYPES, _ptr, _stream
 from . import _lib, dp
 
+BOTH, ONLY_A, ONLY_B, NONE = 0, 1, 2, 3
+
+
+def _need_device(t: torch.Tensor) -> None:
+    if t.device.type != "cuda":
+        raise RuntimeError("aecf_amd: the HIP path needs tensors on a ROCm device (no CPU fallback is provided)")
+
 
 def modality_frontend(features: torch.Tensor, drop: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Missing-modality front-end of one modality in ONE kernel pass: rows with
-    ``drop[r]`` set are zeroed (the reference's ``clone()`` + masked write, ``xrays/train_xrays_example.py:173-176``)
-    and ``present[r] = ||row|| > 1e-6`` of the row as written (the reference's presence test, ``:202-203``).
-    Returns ``(features_out, present_bool)``; without ``drop`` the input tensor itself is returned (no copy).
-    Features are data (the reference feeds precomputed CLIP embeddings): no gradient flows to them."""
-    if features.device.type != "cuda":
-        raise RuntimeError("aecf_amd: the HIP path needs tensors on a ROCm device (no CPU fallback is provided)")
+    ``drop[r]`` set are zeroed (ref ``xrays/train_xrays_example.py:173-176``) and ``present[r] = ||row|| > 1e-6`` of the
+    row as written (ref ``:202-203``).  Returns ``(features_out, present_u8)``; without ``drop`` the input tensor itself
+    is returned.  Features are data (precomputed CLIP embeddings in the reference): no gradient flows to them."""
+    _need_device(features)
     if features.dim() != 2 or features.dtype not in _DTYPES:
         raise ValueError("modality_frontend expects a [rows, dim] float32 or bfloat16 tensor")
     lib = _lib.load()
@@ -37,11 +46,141 @@ def modality_frontend(features: torch.Tensor, drop: Optional[torch.Tensor] = Non
     _lib.check(lib.aecf_modality_frontend(rows, dim, _DTYPES[f.dtype], _ptr(f), _ptr(d8),
                                           None if drop is None else _ptr(out), _ptr(present), _stream()),
                "aecf_modality_frontend")
-    return out, present.bool()
+    return out, present
+
+
+class Route:
+    """Routing table of one batch: ``cls[r]`` in {BOTH, ONLY_A, ONLY_B, NONE}, ``slot[r]`` = position of row r inside its
+    class, ``index[c]`` = the rows of class c in ascending order, ``counts`` = the four class sizes (host integers: the one
+    device->host copy of a step)."""
+
+    def __init__(self, present_a: torch.Tensor, present_b: torch.Tensor):
+        _need_device(present_a)
+        lib = _lib.load()
+        rows = present_a.numel()
+        dev = present_a.device
+        pa = present_a.to(torch.uint8).contiguous()
+        pb = present_b.to(device=dev, dtype=torch.uint8).contiguous()
+        self.rows = rows
+        self.cls = torch.empty(rows, dtype=torch.int32, device=dev)
+        self.slot = torch.empty(rows, dtype=torch.int32, device=dev)
+        self._index = torch.empty(3, rows, dtype=torch.int32, device=dev)
+        counts = torch.empty(4, dtype=torch.int32, device=dev)
+        _lib.check(lib.aecf_route_build(rows, _ptr(pa), _ptr(pb), _ptr(self.cls), _ptr(self.slot), _ptr(self._index),
+                                        _ptr(counts), _stream()), "aecf_route_build")
+        self.counts = tuple(int(v) for v in counts.tolist())
+
+    def index(self, c: int) -> torch.Tensor:
+        return self._index[c, :self.counts[c]]
+
+
+def _arr(ctype, values):
+    return (ctype * len(values))(*values)
+
+
+def _rows_gather(jobs: Sequence[Tuple[torch.Tensor, int, torch.Tensor, int, int, int]], row_bytes: int) -> None:
+    """jobs: (src tensor, src pitch bytes, index, dst address, dst pitch bytes, n)."""
+    jobs = [j for j in jobs if j[5] > 0]
+    if not jobs:
+        return
+    lib = _lib.load()
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    _lib.check(lib.aecf_rows_gather(
+        len(jobs), _arr(vp, [j[0].data_ptr() for j in jobs]), _arr(i64, [j[1] for j in jobs]),
+        _arr(vp, [j[2].data_ptr() for j in jobs]), _arr(i64, [j[5] for j in jobs]), _arr(vp, [j[3] for j in jobs]),
+        _arr(i64, [j[4] for j in jobs]), row_bytes, _stream()), "aecf_rows_gather")
+
+
+def _rows_select(route: Route, srcs: Sequence[Optional[Tuple[int, int]]], dst: torch.Tensor, row_bytes: int) -> None:
+    """srcs[c] = (address, pitch bytes) of class c's compact rows or None; dst [rows, *] contiguous, fully written."""
+    lib = _lib.load()
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    ptrs = [None if (s is None or route.counts[c] == 0) else s[0] for c, s in enumerate(srcs)]
+    pitches = [0 if s is None else s[1] for s in srcs]
+    _lib.check(lib.aecf_rows_select(route.rows, row_bytes, _ptr(route.cls), _ptr(route.slot), _arr(vp, ptrs),
+                                    _arr(i64, pitches), _ptr(dst), dst.stride(0) * dst.element_size(), _stream()),
+               "aecf_rows_select")
+
+
+class _PairGather(torch.autograd.Function):
+    """[n_both, 2, E] pool input from the two encoder outputs (what ref :213-214 builds with where + stack)."""
+
+    @staticmethod
+    def forward(ctx, a, b, route):
+        a, b = a.contiguous(), b.contiguous()
+        n, (rows, E), es = route.counts[BOTH], a.shape, a.element_size()
+        out = torch.empty(n, 2, E, dtype=a.dtype, device=a.device)
+        idx = route.index(BOTH)
+        _rows_gather([(a, E * es, idx, out.data_ptr(), 2 * E * es, n),
+                      (b, E * es, idx, out.data_ptr() + E * es, 2 * E * es, n)], E * es)
+        ctx.route = route
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        route = ctx.route
+        d_out = d_out.contiguous()
+        n, _, E = d_out.shape
+        es = d_out.element_size()
+        da = torch.empty(route.rows, E, dtype=d_out.dtype, device=d_out.device)
+        db = torch.empty_like(da)
+        _rows_select(route, [(d_out.data_ptr(), 2 * E * es), None, None], da, E * es)
+        _rows_select(route, [(d_out.data_ptr() + E * es, 2 * E * es), None, None], db, E * es)
+        return da, db, None
+
+
+class _ClassGather(torch.autograd.Function):
+    """Compact rows of one class (the input of a single-modality projection, ref :229-234)."""
+
+    @staticmethod
+    def forward(ctx, src, route, cls):
+        src = src.contiguous()
+        n, W, es = route.counts[cls], src.shape[1], src.element_size()
+        out = torch.empty(n, W, dtype=src.dtype, device=src.device)
+        _rows_gather([(src, W * es, route.index(cls), out.data_ptr(), W * es, n)], W * es)
+        ctx.route, ctx.cls = route, cls
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        route, cls = ctx.route, ctx.cls
+        d_out = d_out.contiguous()
+        W, es = d_out.shape[1], d_out.element_size()
+        d_src = torch.empty(route.rows, W, dtype=d_out.dtype, device=d_out.device)
+        srcs = [None, None, None]
+        srcs[cls] = (d_out.data_ptr(), W * es)
+        _rows_select(route, srcs, d_src, W * es)
+        return d_src, None, None
+
+
+class _BranchSelect(torch.autograd.Function):
+    """fused[r] = the row its branch produced (both -> fusion_proj, only-a -> image_proj, only-b -> text_proj, none -> 0):
+    the three index-assignments of ref :209-234 as one pass that writes every row once."""
+
+    @staticmethod
+    def forward(ctx, both, only_a, only_b, route, width):
+        parts = [p.contiguous() for p in (both, only_a, only_b)]
+        dt, dev = parts[0].dtype, parts[0].device
+        es = parts[0].element_size()
+        out = torch.empty(route.rows, width, dtype=dt, device=dev)
+        _rows_select(route, [(p.data_ptr(), width * es) for p in parts], out, width * es)
+        ctx.route = route
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        route = ctx.route
+        d_out = d_out.contiguous()
+        W, es = d_out.shape[1], d_out.element_size()
+        grads = [torch.empty(route.counts[c], W, dtype=d_out.dtype, device=d_out.device) for c in range(3)]
+        _rows_gather([(d_out, W * es, route.index(c), grads[c].data_ptr(), W * es, route.counts[c]) for c in range(3)],
+                     W * es)
+        return grads[0], grads[1], grads[2], None, None
 
 
 class AECFModel(nn.Module):
-    """ref xrays/train_xrays_example.py:108-237 (same attribute names, same forward contract)."""
+    """Image + text multi-label classifier around the fusion pool (behaviour of ref xrays/train_xrays_example.py:108-237;
+    module names and construction order as there, so seeds and checkpoints carry over)."""
 
     def __init__(self, image_dim: int = 512, text_dim: int = 512, num_classes: int = 80, hidden_dim: int = 256):
         super().__init__()
@@ -49,84 +188,77 @@ class AECFModel(nn.Module):
         self.hidden_dim = hidden_dim
         self.curriculum_enabled = False
         self.missing_modality_training = False
-        self.image_encoder = nn.Sequential(nn.Linear(image_dim, hidden_dim), nn.ReLU(), nn.Dropout(0.1))   # ref :119-123
-        self.text_encoder = nn.Sequential(nn.Linear(text_dim, hidden_dim), nn.ReLU(), nn.Dropout(0.1))     # ref :125-129
-        self.curriculum_masking = CurriculumMasking(base_mask_prob=0.15)                                     # ref :132
-        self.attention_pool = MultimodalAttentionPool(embed_dim=hidden_dim, num_heads=4,                     # ref :133-138
-                                                      curriculum_masking=None, batch_first=True)
-        self.fusion_query = nn.Parameter(torch.randn(1, 1, hidden_dim) * 0.02)                               # ref :139
-        self.image_proj = nn.Linear(hidden_dim, hidden_dim * 2)                                              # ref :142-143
+        enc = lambda d: nn.Sequential(nn.Linear(d, hidden_dim), nn.ReLU(), nn.Dropout(0.1))
+        self.image_encoder = enc(image_dim)
+        self.text_encoder = enc(text_dim)
+        self.curriculum_masking = CurriculumMasking(base_mask_prob=0.15)
+        self.attention_pool = MultimodalAttentionPool(embed_dim=hidden_dim, num_heads=4, curriculum_masking=None,
+                                                      batch_first=True)
+        self.fusion_query = nn.Parameter(torch.randn(1, 1, hidden_dim) * 0.02)
+        self.image_proj = nn.Linear(hidden_dim, hidden_dim * 2)
         self.text_proj = nn.Linear(hidden_dim, hidden_dim * 2)
-        self.fusion_proj = nn.Linear(hidden_dim, hidden_dim * 2)                                             # ref :146
-        self.classifier = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.ReLU(), nn.Dropout(0.1),   # ref :149-154
+        self.fusion_proj = nn.Linear(hidden_dim, hidden_dim * 2)
+        self.classifier = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.ReLU(), nn.Dropout(0.1),
                                         nn.Linear(hidden_dim, num_classes))
 
-    def _simulate_missing_modalities(self, image_features, text_features, missing_prob: float = 0.3):
-        """ref :156-172 -- which rows lose which modality (never both); same RNG consumption as the reference.
-        The zeroing itself (:173-176) happens in ``modality_frontend`` together with the presence test."""
-        if not (self.training and self.missing_modality_training):
-            return None, None
-        batch_size = image_features.size(0)
-        mask_image = torch.rand(batch_size, device=image_features.device) < missing_prob
-        mask_text = torch.rand(batch_size, device=text_features.device) < missing_prob
-        both_masked = mask_image & mask_text
-        if both_masked.any():
-            keep_image = torch.rand(int(both_masked.sum()), device=image_features.device) > 0.5
-            mask_image[both_masked] = ~keep_image
-            mask_text[both_masked] = keep_image
-        return mask_image, mask_text
-
     def toggle_curriculum(self, enabled: bool) -> None:
-        """ref :179-187 (without the prints)."""
         self.curriculum_enabled = enabled
         self.attention_pool.curriculum_masking = self.curriculum_masking if enabled else None
 
-    def forward(self, image_features, text_features, return_info: bool = False):
-        """ref :189-237."""
-        batch_size = image_features.size(0)
+    def draw_missing(self, batch_size: int, device, missing_prob: float = 0.3, generator=None):
+        """Which rows lose which modality in this step (ref :156-172): each modality independently with probability
+        ``missing_prob``; a row that would lose both keeps one of them, chosen by a fair coin.  Branch-free on the device:
+        three uniform vectors are always drawn (the reference draws the third only for the rows that need it, which costs it a
+        host synchronisation; the distribution is the same, the default generator advances by 3B instead of 2B + k)."""
+        u = torch.rand(3, batch_size, device=device, generator=generator)
+        drop_a, drop_b = u[0] < missing_prob, u[1] < missing_prob
+        clash, keep_a = drop_a & drop_b, u[2] > 0.5
+        return drop_a & ~(clash & keep_a), drop_b & ~(clash & ~keep_a)
+
+    def forward(self, image_features: torch.Tensor, text_features: torch.Tensor, return_info: bool = False, *,
+                mask_uniforms: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
+        """``mask_uniforms`` / ``generator`` are handed to the pool's curriculum masking (``[n_both, 1, 2]``)."""
+        drop_a = drop_b = None
+        if self.training and self.missing_modality_training:
+            drop_a, drop_b = self.draw_missing(image_features.size(0), image_features.device, generator=generator)
+        image_features, has_a = modality_frontend(image_features, drop_a)
+        text_features, has_b = modality_frontend(text_features, drop_b)
+        route = Route(has_a, has_b)
+        enc_a = self.image_encoder(image_features)
+        enc_b = self.text_encoder(text_features)
+        width = 2 * self.hidden_dim
+
         info: Dict[str, torch.Tensor] = {}
-        drop_img, drop_txt = self._simulate_missing_modalities(image_features, text_features)
-        image_features, img_present = modality_frontend(image_features, drop_img)          # ref :173-176 + :202
-        text_features, txt_present = modality_frontend(text_features, drop_txt)           # ref :173-176 + :203
-        img_encoded = self.image_encoder(image_features)
-        txt_encoded = self.text_encoder(text_features)
-        both_present = img_present & txt_present
-        only_img = img_present & ~txt_present
-        only_txt = ~img_present & txt_present
-        fused_features = torch.zeros(batch_size, self.hidden_dim * 2, device=image_features.device,
-                                     dtype=img_encoded.dtype)
-        if both_present.any():                                                  # ref :212-226
-            indices = torch.where(both_present)[0]
-            modalities = torch.stack([img_encoded[indices], txt_encoded[indices]], dim=1)
-            query = self.fusion_query.expand(len(indices), -1, -1)
-            attn_output, attn_info = self.attention_pool(query=query, key=modalities, value=modalities,
-                                                         return_info=True)
-            fused_features[indices] = self.fusion_proj(attn_output.squeeze(1))
+        if route.counts[BOTH] > 0:
+            pairs = _PairGather.apply(enc_a, enc_b, route)
+            pooled, pool_info = self.attention_pool(self.fusion_query.expand(route.counts[BOTH], -1, -1), pairs, pairs,
+                                                    return_info=True, uniforms=mask_uniforms, generator=generator)
+            from_both = self.fusion_proj(pooled.squeeze(1))
             if return_info:
-                info.update(attn_info)
-        if only_img.any():                                                      # ref :228-234
-            indices = torch.where(only_img)[0]
-            fused_features[indices] = self.image_proj(img_encoded[indices])
-        if only_txt.any():
-            indices = torch.where(only_txt)[0]
-            fused_features[indices] = self.text_proj(txt_encoded[indices])
-        logits = self.classifier(fused_features)
+                info.update(pool_info)
+        else:
+            from_both = enc_a.new_zeros(0, width)
+        from_a = self.image_proj(_ClassGather.apply(enc_a, route, ONLY_A)) if route.counts[ONLY_A] else enc_a.new_zeros(0, width)
+        from_b = self.text_proj(_ClassGather.apply(enc_b, route, ONLY_B)) if route.counts[ONLY_B] else enc_a.new_zeros(0, width)
+        fused = _BranchSelect.apply(from_both, from_a, from_b, route, width)
+        logits = self.classifier(fused)
         return (logits, info) if return_info else logits
 
 
 def train_step(model: AECFModel, optimizer: torch.optim.Optimizer, criterion: nn.Module, images: torch.Tensor,
                texts: torch.Tensor, labels: torch.Tensor, bucket: Optional[dp.FlatGradBucket] = None,
-               ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-    """One optimisation step of ref :360-377 (zero_grad -> forward(return_info=True) -> BCE -> backward -> step).
-    With a FlatGradBucket (data parallel) the gradients of all ranks are averaged by one all-reduce before
-    the optimizer step."""
+               loss_scale: float = 1.0) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """One optimisation step (ref :360-377: zero_grad, forward with info, BCE, backward, step).  Data parallel: pass the
+    model's FlatGradBucket -- all gradients of all ranks are then averaged by one all-reduce before the optimizer step;
+    ``loss_scale`` = ``world * b_local / B_global`` makes that average the gradient of the global-batch mean loss when
+    the shards are uneven (1.0 for even shards)."""
     if bucket is None:
         optimizer.zero_grad(set_to_none=True)
     else:
         bucket.zero()
     logits, info = model(images, texts, return_info=True)
     loss = criterion(logits, labels)
-    loss.backward()
+    (loss * loss_scale if loss_scale != 1.0 else loss).backward()
     if bucket is not None:
         bucket.all_reduce(average=True)
     optimizer.step()

@@ -7,8 +7,13 @@ per GPU over RCCL).  Rank 0 prints ONE JSON line.
 Workload (BASELINE.json configs[1], the config the metric is quoted on): synthetic
 x[B=65536, M=3, d=512] bf16, 8 heads, mask_prob 0.15, curriculum masking in training mode.
 One "step" = pool(query.expand(B), x, return_info=True) + entropy_loss(info['entropy']) + backward with a
-resident upstream gradient dy, all inputs resident in HBM.  N>1: every rank runs its own B samples (weak
-scaling) and the parameter gradients (4E^2+5E floats) are all-reduced over RCCL inside the step.
+resident upstream gradient dy, all inputs resident in HBM.  N>1: one process per GPU; `--scaling weak` (default)
+gives every rank its own B samples, `--scaling strong` shards the global B=65536 across the ranks; the parameter
+gradients (4E^2+5E values) are all-reduced over RCCL inside the step and every rank consumes ITS rows of one global
+uniform tensor for the curriculum mask (N-rank masks == 1-rank masks).
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (child processes, started before this process
+touches the GPU) and relays rank 0's JSON line; under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
 import ctypes
@@ -36,9 +41,10 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16
+PROFILE_TAG = "r02"            # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
 
 
-def make_inputs(cfg, device):
+def make_inputs(cfg, device, seed_offset=0):
     B, M, E, H, dtype, p = cfg
     import aecf_amd
     torch.manual_seed(2)
@@ -49,18 +55,18 @@ def make_inputs(cfg, device):
         query.copy_(torch.randn(1, 1, E, generator=torch.Generator().manual_seed(1)) * (2.0 / E) ** 0.5)
     pool = pool.to(device=device, dtype=dtype)
     query = torch.nn.Parameter(query.detach().to(device=device, dtype=dtype))
-    g = torch.Generator(device=device).manual_seed(0)
+    g = torch.Generator(device=device).manual_seed(seed_offset)      # every rank its own samples
     x = torch.randn(B, M, E, device=device, generator=g).to(dtype).requires_grad_(True)
     dy = torch.randn(B, 1, E, device=device, generator=g).to(dtype)
     pool.train()
     return pool, query, x, dy
 
 
-def step(pool, query, x, dy, params, dp_on):
+def step(pool, query, x, dy, params, dp_on, uniforms=None):
     """One pass of the hot path over one resident batch: forward (+ entropy_loss) + backward (+ the one
     gradient all-reduce when data-parallel)."""
     B = x.shape[0]
-    out, info = pool(query.expand(B, -1, -1), x, return_info=True)
+    out, info = pool(query.expand(B, -1, -1), x, return_info=True, uniforms=uniforms)
     ent_loss = pool.curriculum_masking.entropy_loss(info["entropy"])
     x.grad = None
     for p in params:
@@ -126,7 +132,9 @@ def stage_model(cfg):
     s = 2 if dtype == torch.bfloat16 else 4
     return {
         "fwd.gate":    dict(bytes=s * M * E, flops=2 * M * E * 16 * (2 if s == 2 else 1)),
-        "fwd.vproj":   dict(bytes=s * (2 * M + 1) * E, flops=2 * M * E * E),  # reads x, writes V (kept for the backward) and o
+        # reads x, writes o.  (The V it also stores for the backward is NOT algorithmic: SURVEY 8d "recompute instead of
+        # saving K/V"; it shows up in roofline.traffic.)
+        "fwd.vproj":   dict(bytes=s * (M + 1) * E, flops=2 * M * E * E),
         "fwd.outproj": dict(bytes=s * 2 * E, flops=2 * E * E),
         "bwd.dout":    dict(bytes=s * 2 * E, flops=2 * E * E),
         "bwd.dw_out":  dict(bytes=s * 2 * E, flops=2 * E * E),
@@ -171,20 +179,56 @@ def cpu_baseline(cfg, seconds_budget=20.0):
                 sample=f"{n} samples of the same [B,M={M},d={E}] workload, fp32, fwd+bwd, best of {reps}")
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as child processes BEFORE this process
+    has touched the GPU (it never does), relay their output, exit with the worst return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = B per GPU fixed (default), strong = the config's B is the GLOBAL batch, sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
     dev_index = local % max(ndev, 1)          # rehearsal on a 1-GPU box: several ranks may share device 0
+    backend = None
     if world > 1:
         import torch.distributed as dist
         # RCCL ("nccl") over xGMI is the real path; AECF_DIST_BACKEND=gloo only rehearses the N>1 code on one GPU
@@ -195,11 +239,27 @@ def main():
             dist.init_process_group(backend)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    cfg = CONFIGS[args.config]
-    B, M, E, H, dtype, p = cfg
-    pool, query, x, dy = make_inputs(cfg, device)
+    from aecf_amd import dp
+    Bc, M, E, H, dtype, p = CONFIGS[args.config]
+    if args.scaling == "strong" and world > 1:
+        lo, hi = dp.shard_bounds(Bc, rank, world)
+        B, B_global = hi - lo, Bc
+    else:
+        lo, B, B_global = rank * Bc, Bc, world * Bc
+    cfg = (B, M, E, H, dtype, p)
+    pool, query, x, dy = make_inputs(cfg, device, seed_offset=rank)
     params = [query] + list(pool.parameters())
-    bucket = world > 1                      # data-parallel: gradients are all-reduced inside the step
+    if world > 1:
+        dp.broadcast_parameters(params)      # replicas start identical whatever the ranks' construction RNG did
+        dp.probe_avg_support(params[0].dtype, device)
+    # curriculum-mask uniforms: every rank draws the SAME global tensor (shared seed, own generator) and uses its rows
+    ugen = torch.Generator(device=device).manual_seed(1234) if world > 1 else None
+
+    def one_step():
+        u = None
+        if ugen is not None:
+            u = torch.rand(B_global, 1, M, device=device, dtype=torch.float32, generator=ugen)[lo:lo + B]
+        return step(pool, query, x, dy, params, world > 1, u)
 
     def barrier():
         if world > 1:
@@ -208,68 +268,85 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(pool, query, x, dy, params, bucket)
+        one_step()
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (same stream)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(pool, query, x, dy, params, bucket)
+    marks[0].record()
+    for i in range(args.steps):
+        one_step()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2]
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
 
-    # per-stage durations (HIP events on the launch stream), measured live over extra steps after the timed region
+    # per-stage durations (HIP events the library records on its launch stream), measured live over extra steps after
+    # the timed region
     roofline = None
     stages = None
     if rank == 0:
         st = StageTimer()
         for _ in range(min(args.steps, 20)):
             st.arm()
-            step(pool, query, x, dy, params, False)
+            step(pool, query, x, dy, params, False, None)
             st.disarm()
             torch.cuda.synchronize()
             st.collect()
         stages = st.mean_ms()
         model = stage_model(cfg)
         dom = max((k for k in stages if k in model), key=lambda k: stages[k])
-        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # corrected as MI355X_MICROARCH.md prescribes); null when no counter pass exists for this config
+        # HBM bytes per launch of that stage from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # corrected as MI355X_MICROARCH.md prescribes); measured at the config's full per-GPU batch
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"r01_v7_{args.config}_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{args.config}_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f)["bytes_per_launch"].get(dom)
+            if traffic is not None and B != Bc:
+                traffic = traffic * B / Bc
         t_s = stages[dom] * 1e-3
         gbs = model[dom]["bytes"] * B / t_s / 1e9
         tfl = model[dom]["flops"] * B / t_s / 1e12
+        both = dict(hbm_frac=gbs / HBM_PEAK_GBS, mfma_frac=tfl / MFMA_PEAK_TFLOPS, alg_GBps=gbs, executed_TFLOPs=tfl)
         if gbs / HBM_PEAK_GBS >= tfl / MFMA_PEAK_TFLOPS:
             roofline = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                            traffic=traffic, kernel=dom, kernel_ms=stages[dom])
+                            traffic=traffic, kernel=dom, kernel_ms=stages[dom], **both)
         else:
             roofline = dict(bound="mfma", achieved=tfl, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=tfl / MFMA_PEAK_TFLOPS, traffic=traffic, kernel=dom, kernel_ms=stages[dom])
+                            frac=tfl / MFMA_PEAK_TFLOPS, traffic=traffic, kernel=dom, kernel_ms=stages[dom], **both)
 
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
+        sec = elapsed / args.steps
         s_bytes = 2 if dtype == torch.bfloat16 else 4
-        path_bytes = s_bytes * E * (3 * M + 2)
+        path_bytes = s_bytes * E * (3 * M + 2)                    # fwd+bwd algorithmic bytes per sample
+        path_flops = sum(v["flops"] for v in stage_model(cfg).values())     # MFMA flops this decomposition executes
+        cb = None
+        if not (args.no_cpu_baseline or world > 1):
+            cb = cpu_baseline(cfg)
+            cb["cpu_model"] = cpu_model()
         line = {
-            "metric": "fused samples/sec (fwd+bwd)", "value": world * B / (elapsed / args.steps), "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "fused samples/sec (fwd+bwd)", "value": B_global / sec, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+            "ms_per_step_median": median_ms,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: [B={B} per GPU, M={M}, d={E}, {H} heads] mask_prob={p} "
-                                   "train-mode curriculum masking, fwd+bwd", "global_batch": world * B,
-                       "parallelism": f"dp{world}"},
+                                   "train-mode curriculum masking, fwd+bwd", "global_batch": B_global,
+                       "parallelism": f"dp{world}", "world_size": world,
+                       "collectives": None if world == 1 else f"{backend}: 1 all-reduce of {4 * E * E + 5 * E} grads/step"},
             "roofline": roofline,
-            "path_hbm_frac": path_bytes * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "path_hbm_frac": path_bytes * B / sec / 1e9 / HBM_PEAK_GBS,
+            "path_mfma_frac": path_flops * B / sec / 1e12 / MFMA_PEAK_TFLOPS,
             "stage_ms": stages,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(cfg),
+            "cpu_baseline": cb,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()                 # rank 0 is still measuring its stage times: leave together

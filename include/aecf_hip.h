@@ -267,6 +267,25 @@ int aecf_mha_backward(const aecf_mha_desc* d, const aecf_mha_bwd_args* a, void* 
 int aecf_modality_frontend(int64_t rows, int32_t dim, int32_t dtype, const void* feat, const uint8_t* drop,
                            void* out, uint8_t* present, void* stream);
 
+/* ---- presence routing around the pool (ref xrays/train_xrays_example.py:205-234) ----
+ * The reference routes rows with boolean masks + torch.where + torch.stack + index_put.  Here: one routing table built on
+ * the device, then row moves driven by it.
+ *   aecf_route_build: class of every row from the two presence vectors -- 0 both present (:205), 1 only a (:206),
+ *     2 only b (:207), 3 neither -- its slot inside its class (ascending row order, what torch.where yields), the inverse
+ *     lists index[c*rows + slot] = row for c = 0..2, and counts[4] (the only values the host reads back).
+ *   aecf_rows_gather: up to 3 jobs dst_j[i] = src_j[index_j[i]], i < n_j, in ONE launch (rows of row_bytes bytes; pitches in
+ *     bytes).  E.g. the [n_both, 2, E] pool input of :213-216 = two jobs writing the halves of one destination row.
+ *   aecf_rows_select: dst[r] = src_{route[r]}[slot[r]] (class 3 or a NULL source: zeros); EVERY row of dst is written once,
+ *     so no memset / index_put is needed (the fused [B, 2E] rows of :209-234; the backward of a gather). */
+int aecf_route_build(int64_t rows, const uint8_t* present_a, const uint8_t* present_b, int32_t* route,
+                     int32_t* slot, int32_t* index, int32_t* counts, void* stream);
+int aecf_rows_gather(int32_t njobs, const void* const* src, const int64_t* src_pitch,
+                     const int32_t* const* index, const int64_t* n, void* const* dst,
+                     const int64_t* dst_pitch, int64_t row_bytes, void* stream);
+int aecf_rows_select(int64_t rows, int64_t row_bytes, const int32_t* route, const int32_t* slot,
+                     const void* const* src, const int64_t* src_pitch, void* dst, int64_t dst_pitch,
+                     void* stream);
+
 /* ---- contrastive term (BASELINE.json north_star; NOT in the reference: SURVEY.md 8a row A9, build-defined) ----
  * Row-wise L2 normalisation zn = z / max(||z||, eps) and its backward dz = (dzn - zn (dzn.zn)) * inv_norm. */
 int aecf_l2norm_forward(int64_t n, int32_t d, int32_t dtype, float eps, const void* z, void* zn,

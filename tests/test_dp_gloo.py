@@ -54,8 +54,23 @@ def _worker(rank, world, port, q):
         (z_all * w).sum().backward()
         u = dp.global_uniforms(B, 1, 3, seed=123, device="cpu")
         mean_stat = dp.all_reduce_mean_scalar(x[lo:hi].mean(), weight=hi - lo)
+        # replicas built under different RNG states are made identical by broadcast_parameters
+        torch.manual_seed(100 + rank)
+        other = torch.nn.Linear(5, 3)
+        dp.broadcast_parameters(list(other.parameters()))
+        # uneven shards + per-shard MEAN loss: shard_loss_scale makes the unweighted average the global-mean gradient
+        B2 = 23
+        x2, t2 = torch.randn(B2, 16, generator=torch.Generator().manual_seed(7)), torch.randn(
+            B2, 8, generator=torch.Generator().manual_seed(8))
+        lo2, hi2 = dp.shard_bounds(B2, rank, world)
+        m2 = _model()
+        loss2 = ((m2(x2[lo2:hi2]) - t2[lo2:hi2]) ** 2).mean() * dp.shard_loss_scale(hi2 - lo2, B2, world)
+        loss2.backward()
+        avg_ok = dp.probe_avg_support(torch.float32, torch.device("cpu"))
+        dp.all_reduce_grads(list(m2.parameters()))
         q.put((rank, [g.numpy() for g in grads], z_all.detach().numpy(), z.grad.numpy(),
-               dp.shard_batch(u, rank, world).numpy(), float(mean_stat), (lo, hi)))
+               dp.shard_batch(u, rank, world).numpy(), float(mean_stat), (lo, hi),
+               [p.detach().numpy() for p in other.parameters()], [p.grad.numpy() for p in m2.parameters()], avg_ok))
     finally:
         dist.destroy_process_group()
 
@@ -83,7 +98,18 @@ def test_dp_world2_matches_single_process():
     ref = [p.grad for p in model.parameters()]
     u = dp.global_uniforms(B, 1, 3, seed=123, device="cpu")
     w = torch.arange(B * 4, dtype=torch.float32).reshape(B, 4)
-    for rank, grads, z_all, dz, u_shard, mean_stat, (lo, hi) in res:
+    B2 = 23
+    x2, t2 = torch.randn(B2, 16, generator=torch.Generator().manual_seed(7)), torch.randn(
+        B2, 8, generator=torch.Generator().manual_seed(8))
+    m2 = _model()
+    ((m2(x2) - t2) ** 2).mean().backward()
+    ref2 = [p.grad for p in m2.parameters()]
+    for rank, grads, z_all, dz, u_shard, mean_stat, (lo, hi), bcast, grads2, avg_ok in res:
+        assert not avg_ok                                                              # gloo: sum + divide, agreed by all
+        for a, b in zip(bcast, res[0][7]):
+            assert (a == b).all()                                                      # replicas identical to rank 0's
+        for g, r in zip(grads2, ref2):
+            assert torch.allclose(torch.from_numpy(g), r, rtol=1e-5, atol=1e-6)        # uneven shards, mean loss
         for g, r in zip(grads, ref):
             assert torch.allclose(torch.from_numpy(g), r, rtol=1e-5, atol=1e-6)       # all-reduced == full batch
         assert torch.allclose(torch.from_numpy(z_all), x[:, :4])                       # gathered in rank order

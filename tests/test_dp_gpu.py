@@ -1,0 +1,142 @@
+"""Data-parallel fusion path on the GPU: two ranks run the FUSED kernels on their batch shards
+and must reproduce the single-rank full-batch result -- gradients (after the one all-reduce) equal, masks bit-equal.
+
+Two ranks on two GPUs use RCCL ("nccl"); on a one-GPU box both ranks share device 0 and rendezvous over gloo (the
+collective payload is then staged through the host by torch, the kernels and the plumbing under test are the same).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+B, M, E, H = 1000, 3, 128, 4           # uneven-free global batch of the two-rank run; d_attn_w path exercised too
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _inputs(dtype):
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(B, M, E, generator=g) * torch.tensor([1.0, 1.6, 2.2]).view(1, 3, 1)).to(dtype)
+    dy = torch.randn(B, 1, E, generator=g).to(dtype)
+    return x, dy
+
+
+def _build(dev, dtype, seed):
+    import aecf_amd
+    torch.manual_seed(seed)
+    query, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=0.3, num_heads=H)
+    with torch.no_grad():
+        pool.attention.in_proj_bias.normal_(0, 0.05)
+    pool = pool.to(dev, dtype).train()
+    query = torch.nn.Parameter(query.detach().to(dev, dtype))
+    return query, pool
+
+
+def _run_shard(query, pool, x, dy, u, dev, scale):
+    xs = x.to(dev).requires_grad_(True)
+    out, info = pool(query.expand(xs.shape[0], -1, -1), xs, return_info=True, uniforms=u)
+    ent = pool.curriculum_masking.entropy_loss(info["entropy"])
+    loss = ((out.float() * dy.to(dev).float()).sum() / B + 1e-2 * info["attention_weights"].float().pow(2).sum() / B
+            + 0.0 * ent) * scale
+    loss.backward()
+    return out.detach(), info["masked_attention_weights"].detach(), xs.grad
+
+
+def _worker(rank, world, port, backend, dtype, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from aecf_amd import dp
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, dy = _inputs(dtype)
+        query, pool = _build(dev, dtype, seed=50 + rank)           # replicas differ until the broadcast
+        params = [query] + list(pool.parameters())
+        dp.broadcast_parameters(params)
+        dp.probe_avg_support(params[0].dtype, dev)
+        lo, hi = dp.shard_bounds(B, rank, world)
+        u = dp.shard_batch(dp.global_uniforms(B, 1, M, seed=77, device=dev), rank, world)
+        # the loss is a SUM over the shard divided by the global B, so the average over ranks needs the factor `world`
+        out, masked, dx = _run_shard(query, pool, x[lo:hi], dy[lo:hi], u, dev, float(world))
+        dp.all_reduce_grads(params)
+        torch.cuda.synchronize()
+        q.put((rank, lo, hi, out.float().cpu().numpy(), masked.float().cpu().numpy(), dx.float().cpu().numpy(),
+               [p.grad.float().cpu().numpy() for p in params], [p.detach().float().cpu().numpy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_ranks_equal_one_rank(dtype):
+    from aecf_amd import dp
+    world = 2
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    # single rank, full batch, rank 0's parameters, the same global uniforms
+    dev = torch.device("cuda:0")
+    x, dy = _inputs(dtype)
+    query, pool = _build(dev, dtype, seed=50)
+    params = [query] + list(pool.parameters())
+    for p, v in zip(params, res[0][7]):
+        assert torch.equal(p.detach().float().cpu(), torch.from_numpy(v))            # broadcast: rank 0's values
+    for a, b in zip(res[0][7], res[1][7]):
+        assert (a == b).all()
+    u = dp.global_uniforms(B, 1, M, seed=77, device=dev)
+    out, masked, dx = _run_shard(query, pool, x, dy, u, dev, 1.0)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2       # bf16: parameter gradients are rounded to bf16 per rank
+    for rank, lo, hi, o_r, m_r, dx_r, grads, _ in res:
+        assert torch.equal(torch.from_numpy(o_r), out[lo:hi].float().cpu())           # per-sample outputs bit-equal
+        assert torch.equal(torch.from_numpy(m_r), masked[lo:hi].float().cpu())        # masks independent of N
+        assert torch.equal(torch.from_numpy(dx_r), dx[lo:hi].float().cpu())
+        for g, p in zip(grads, params):
+            ref = p.grad.float().cpu()
+            err = (torch.from_numpy(g) - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert err < tol, (rank, tuple(ref.shape), err)
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus2_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself and reports n_gpus = 2 (one GPU: both ranks
+    share it over gloo; two or more: RCCL)."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if torch.cuda.device_count() < 2:
+        env["AECF_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "5",
+                        "--warmup", "2", "--scaling", "strong"], env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["global_batch"] == 4096 and line["value"] > 0

@@ -115,9 +115,7 @@ def test_general_path_with_curriculum_masking_info_contract():
     x = (torch.randn(B, M, E, generator=g) * torch.tensor([1.0, 2.0, 3.0]).view(1, 3, 1)).to(DEV)
     q = torch.randn(B, T, E, generator=g).to(DEV)
     U = torch.rand(B, T, M, generator=g)
-    layer._uniforms_override = U
-    y, info = pool(q, x, return_info=True)
-    layer._uniforms_override = None
+    y, info = pool(q, x, return_info=True, uniforms=U)
     assert y.shape == (B, T, E)
     assert set(info) == {"entropy", "mask_rate", "target_entropy", "attention_weights", "masked_attention_weights"}
     assert info["attention_weights"].shape == (B, T, M) and info["attention_weights"].requires_grad

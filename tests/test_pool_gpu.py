@@ -124,8 +124,7 @@ def test_mask_stage_bit_exact(name):
     mod = aecf_amd.CurriculumMasking(base_mask_prob=float(g["p_base"]), min_active=int(g["min_active"])).to(dev)
     mod.train()
     w = t(g["weights"]).to(dev).requires_grad_(True)
-    layer._uniforms_override = t(g["uniforms"])
-    masked, info = mod(w)
+    masked, info = mod(w, uniforms=t(g["uniforms"]))
     (masked * t(g["d_masked"]).to(dev)).sum().backward()
     torch.cuda.synchronize()
     assert torch.equal((masked != 0).cpu(), torch.from_numpy(g["nonzero"])), "mask pattern differs"
@@ -148,9 +147,7 @@ def test_mask_edges():
         p, tau, k = g[f"{key}.kw"]
         mod = aecf_amd.CurriculumMasking(float(p), float(tau), int(k)).to(dev)
         mod.train()
-        layer._uniforms_override = t(g[f"{key}.U"])
-        masked, info = mod(t(g[f"{key}.w"]).to(dev))
-        layer._uniforms_override = None
+        masked, info = mod(t(g[f"{key}.w"]).to(dev), uniforms=t(g[f"{key}.U"]))
         nn = lambda a: torch.nan_to_num(torch.as_tensor(a), nan=123.0)
         assert torch.allclose(nn(masked.cpu()), nn(t(g[f"{key}.masked"])), rtol=1e-6, atol=1e-8), key
         assert torch.allclose(nn(info["entropy"].cpu()), nn(t(g[f"{key}.entropy"])), rtol=1e-5, atol=1e-6), key
@@ -220,8 +217,7 @@ def test_g1_plumbing_readme_pattern():
     query = query.detach().to(dev).requires_grad_(True)
     x = torch.randn(32, 2, 512, generator=torch.Generator().manual_seed(int(g["seed_x"]))).to(dev)
     pool.train()
-    layer._uniforms_override = t(g["uniforms"])
-    out, info = pool(query.expand(32, -1, -1), x, return_info=True)
+    out, info = pool(query.expand(32, -1, -1), x, return_info=True, uniforms=t(g["uniforms"]))
     assert out.shape == (32, 1, 512)
     assert sorted(info.keys()) == list(g["train_keys"])
     assert rel_err(out.detach().cpu(), g["out"]) < FP32_TOL
@@ -396,8 +392,7 @@ def test_g10_model_step_matches_reference():
             m.p = 0.0
     model = model.to(dev).train()
     images, texts, labels = (t(g[k]).to(dev) for k in ("images", "texts", "labels"))
-    layer._uniforms_override = t(g["uniforms"])
-    logits, info = model(images, texts, return_info=True)
+    logits, info = model(images, texts, return_info=True, mask_uniforms=t(g["uniforms"]))
     loss = torch.nn.BCEWithLogitsLoss()(logits, labels)
     loss.backward()
     assert rel_err(logits.detach().cpu(), g["logits"]) < 2e-5
@@ -460,32 +455,82 @@ def test_modality_frontend_matches_reference_ops():
             want[drop] = 0
             want_present = torch.norm(want.float(), dim=1) > 1e-6
             out, present = modality_frontend(f.to(dev), drop.to(dev))
-            assert torch.equal(out.cpu(), want) and torch.equal(present.cpu(), want_present), (dtype, rows, dim)
+            assert torch.equal(out.cpu(), want) and torch.equal(present.cpu().bool(), want_present), (dtype, rows, dim)
             out2, present2 = modality_frontend(f.to(dev), None)  # evaluation: presence only, no copy
-            assert torch.equal(out2.cpu(), f) and torch.equal(present2.cpu(), torch.norm(f.float(), dim=1) > 1e-6)
+            assert torch.equal(out2.cpu(), f) and torch.equal(present2.cpu().bool(), torch.norm(f.float(), dim=1) > 1e-6)
 
 
-def test_model_missing_modality_training_routes_like_reference_ops():
-    """AECFModel with missing_modality_training: same RNG consumption and the same routing decisions as the reference's
-    ops (drop masks from the same torch.rand calls; presence from the zeroed rows)."""
+def test_model_missing_modality_training_routing():
+    """AECFModel with missing_modality_training (ref xrays/train_xrays_example.py:156-177): a row never loses both
+    modalities, each is dropped with probability ~0.3, and the forward routes exactly the rows the draw decided
+    (the same generator state gives the same draw inside the model)."""
     from aecf_amd.xray import AECFModel
     dev = _dev()
     torch.manual_seed(5)
     model = AECFModel(64, 48, 5, 64).to(dev).train()
     model.missing_modality_training = True
     model.toggle_curriculum(True)
-    img, txt = torch.randn(300, 64, device=dev), torch.randn(300, 48, device=dev)
+    img, txt = torch.randn(3000, 64, device=dev), torch.randn(3000, 48, device=dev)
     torch.manual_seed(9)
-    di, dt_ = model._simulate_missing_modalities(img, txt)
-    assert not bool((di & dt_).any()) and 0.15 < float(di.float().mean()) < 0.45
-    state = torch.cuda.get_rng_state(dev)
+    di, dt_ = model.draw_missing(3000, dev)
+    assert not bool((di & dt_).any())
+    # P(drop a) = p - p^2/2 = 0.255 (a clash keeps a with probability 1/2)
+    assert 0.21 < float(di.float().mean()) < 0.30 and 0.21 < float(dt_.float().mean()) < 0.30
     torch.manual_seed(9)
     logits, info = model(img, txt, return_info=True)
     both = int((~di & ~dt_).sum())
-    assert logits.shape == (300, 5) and info["attention_weights"].shape == (both, 1, 2)
+    assert logits.shape == (3000, 5) and info["attention_weights"].shape == (both, 1, 2)
     assert torch.isfinite(logits).all()
     logits.sum().backward()
     assert model.fusion_query.grad is not None and torch.isfinite(model.fusion_query.grad).all()
+
+
+def test_routing_kernels_match_torch_indexing():
+    """aecf_route_build / aecf_rows_gather / aecf_rows_select against the reference's torch.where + stack + index_put
+    (ref xrays/train_xrays_example.py:205-234), forward and backward, float32 and bfloat16, odd widths."""
+    from aecf_amd import xray
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    for dtype, rows, E in ((torch.float32, 1, 8), (torch.float32, 2500, 64), (torch.bfloat16, 777, 256),
+                           (torch.bfloat16, 130, 7)):
+        pa = torch.rand(rows, generator=g) < 0.7
+        pb = torch.rand(rows, generator=g) < 0.6
+        route = xray.Route(pa.to(dev), pb.to(dev))
+        both, oa, ob = pa & pb, pa & ~pb, ~pa & pb
+        assert route.counts == (int(both.sum()), int(oa.sum()), int(ob.sum()), int((~pa & ~pb).sum()))
+        for c, m in enumerate((both, oa, ob)):
+            assert torch.equal(route.index(c).cpu().long(), torch.where(m)[0])
+        a = torch.randn(rows, E, generator=g).to(dtype)
+        b = torch.randn(rows, E, generator=g).to(dtype)
+        ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        pairs = xray._PairGather.apply(ad, bd, route)
+        ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        idx = torch.where(both)[0]
+        want = torch.stack([ar[idx], br[idx]], dim=1)
+        assert torch.equal(pairs.detach().cpu(), want.detach())
+        dpair = torch.randn(want.shape, generator=g).to(dtype)
+        pairs.backward(dpair.to(dev))
+        want.backward(dpair)
+        assert torch.equal(ad.grad.cpu(), ar.grad) and torch.equal(bd.grad.cpu(), br.grad)
+        # the three branches written into one [rows, W] tensor
+        W = 2 * E
+        parts = [torch.randn(int(m.sum()), W, generator=g).to(dtype) for m in (both, oa, ob)]
+        pd = [p.to(dev).requires_grad_(True) for p in parts]
+        pr = [p.clone().requires_grad_(True) for p in parts]
+        fused = xray._BranchSelect.apply(pd[0], pd[1], pd[2], route, W)
+        ref = torch.zeros(rows, W, dtype=dtype)
+        for p, m in zip(pr, (both, oa, ob)):
+            if m.any():
+                ref = ref.index_put((torch.where(m)[0],), p)
+        assert torch.equal(fused.detach().cpu(), ref.detach())
+        df = torch.randn(rows, W, generator=g).to(dtype)
+        fused.backward(df.to(dev))
+        ref.backward(df)
+        for p, q in zip(pd, pr):
+            if q.numel():
+                assert torch.equal(p.grad.cpu(), q.grad)
+        one = xray._ClassGather.apply(ad, route, xray.ONLY_A)
+        assert torch.equal(one.detach().cpu(), a[torch.where(oa)[0]])
 
 
 def test_empty_batch_matches_reference_contract():

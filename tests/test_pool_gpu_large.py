@@ -51,8 +51,7 @@ def _run(pool, query, x, dy, U, dtype, dev="cuda:0"):
     for p in pool.parameters():
         p.grad = None
     query.grad = None
-    layer._uniforms_override = U
-    out, info = pool(query.expand(x.shape[0], -1, -1), xd, return_info=True)
+    out, info = pool(query.expand(x.shape[0], -1, -1), xd, return_info=True, uniforms=U)
     torch.autograd.backward([out], [dy.to(dev, dtype)])
     torch.cuda.synchronize()
     a = pool.attention

@@ -58,10 +58,8 @@ def _case(B, M, E, H, dtype, kpm, seed):
     pool = pool.to(dev).train()                       # fp32 master parameters; activations in `dtype`
     xd = x.to(dev, dtype).requires_grad_(True)
     qd = q.to(dev).requires_grad_(True)
-    layer._uniforms_override = U
     out, info = pool(qd.to(dtype).expand(B, -1, -1) if dtype != torch.float32 else qd.expand(B, -1, -1), xd,
-                     key_padding_mask=None if mask is None else mask.to(dev), return_info=True)
-    layer._uniforms_override = None
+                     key_padding_mask=None if mask is None else mask.to(dev), return_info=True, uniforms=U)
     loss = (out.float() * dy.to(dev)).sum() + (info["attention_weights"].float() * dw.to(dev)).sum()
     loss.backward()
     torch.cuda.synchronize()

@@ -15,12 +15,10 @@ x = torch.randn(B, M, E, device=dev, generator=g).to(torch.bfloat16).requires_gr
 dy = torch.randn(B, 1, E, device=dev, generator=g).to(torch.bfloat16)
 U = torch.rand(B, 1, M, device=dev, generator=g)
 def run(n):
-    layer._uniforms_override = U[:n]
     xs = x[:n].detach().requires_grad_(True)
     for p in list(pool.parameters()) + [q]: p.grad = None
-    out, info = pool(q.expand(n, -1, -1), xs, return_info=True)
+    out, info = pool(q.expand(n, -1, -1), xs, return_info=True, uniforms=U[:n])
     out.backward(dy[:n])
-    layer._uniforms_override = None
     torch.cuda.synchronize()
     return out.detach(), info["masked_attention_weights"].detach(), xs.grad, pool.attention.in_proj_weight.grad.clone()
 t0 = time.time(); big = run(B); t1 = time.time()
