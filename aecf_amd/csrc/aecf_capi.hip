@@ -17,6 +17,8 @@ using namespace aecf;
 namespace {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+bool env_no_ws();              // AECF_NO_WS / AECF_NO_GATE_FUSION, read once per process (defined with the graph cache)
+bool env_no_gate_fusion();
 inline int esize(int dtype) { return dtype == AECF_BF16 ? 2 : 4; }
 
 struct FwdWs {
@@ -208,7 +210,7 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     void** ev = a->stage_events;
     mark(ev, 0, s);
     // fragment-major copies of W_v and W_o for the weight-stationary kernels (bf16, E in {256, 512, 768, 1024})
-    const bool frag = d->dtype == AECF_BF16 && (E == 256 || E == 512 || E == 768 || E == 1024) && !getenv("AECF_NO_WS");
+    const bool frag = d->dtype == AECF_BF16 && (E == 256 || E == 512 || E == 768 || E == 1024) && !env_no_ws();
     FragJobs fj;
     if (frag) {
         fj.n = 2;
@@ -241,8 +243,7 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     if (frag) v.w_frag = ws + L.wv_frag;
     // bf16, shapes of the weight-stationary kernel, M <= 3: the scores are formed inside the value projection (one pass
     // over x for both) and the per-sample statistics follow from the saved weights; otherwise the gate kernel runs first
-    static const int no_fuse = getenv("AECF_NO_GATE_FUSION") ? atoi(getenv("AECF_NO_GATE_FUSION")) : 0;   // A/B timing only
-    bool fuse_gate = d->dtype == AECF_BF16 && M <= 3 && !no_fuse && !getenv("AECF_NO_WS");
+    bool fuse_gate = d->dtype == AECF_BF16 && M <= 3 && !env_no_gate_fusion() && !env_no_ws();   // (A/B timing switches)
     if (fuse_gate) {
         v.g_ahi = a_hi; v.g_alo = a_lo; v.g_kpm = a->key_padding_mask;
         if (!gemm_ws_supported(v)) { fuse_gate = false; v.g_ahi = v.g_alo = nullptr; v.g_kpm = nullptr; }
@@ -289,7 +290,7 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
 
     void** ev = a->stage_events;
     mark(ev, 0, s);
-    const bool frag = d->dtype == AECF_BF16 && (E == 256 || E == 512 || E == 768 || E == 1024) && !getenv("AECF_NO_WS");
+    const bool frag = d->dtype == AECF_BF16 && (E == 256 || E == 512 || E == 768 || E == 1024) && !env_no_ws();
     FragJobs fj;
     if (!a->saved_prep) {                             // (with saved_prep the forward already produced all of this)
         if (frag) {                                   // fragment-major W_v^T (dx) and W_o^T (dout)
@@ -368,90 +369,163 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
 
 // ---- executable-graph launch of one call ------------------------------------------------------------------------
 // Small dependent kernels launched one by one on a stream pay ~4 us per boundary on this part and ~3 us of host time
-// each; the same chain replayed as a HIP graph pays ~1.6 us per node (tools/micro/launch_floor.hip, graph_update.hip).  A call is therefore captured on a library-owned stream (the
-// caller's may be the legacy stream, which cannot capture), the cached executable graph of that call shape is updated
-// with the captured one (same topology, new pointers: cheaper than the plain launches it replaces) and launched on
-// the caller's stream.  Arguments are snapshotted at launch, so updating while earlier launches are queued is safe
-// (tools/micro/graph_update_check.hip).  Anything unexpected falls back to the plain launches.
+// each; the same chain replayed as a HIP graph pays ~1.6 us per node (tools/micro/launch_floor.hip, graph_update.hip).
+// A call shape that KEEPS COMING BACK is therefore captured on a library-owned stream of its device (the caller's may be
+// the legacy stream, which cannot capture), the cached executable graph of that shape is updated with the captured one
+// (same topology, new pointers: cheaper than the plain launches it replaces) and launched on the caller's stream.
+// Arguments are snapshotted at launch, so updating while earlier launches are queued is safe
+// (tools/micro/graph_update_check.hip, tests/test_pool_gpu.py::test_graph_replay_back_to_back).
+// Bounded state, all of it behind one mutex:
+//   * a shape is instantiated only after GRAPH_MIN_SIGHTINGS calls with the same key (a caller whose batch changes every
+//     step -- xray.AECFModel feeds the count of both-present rows -- never pays a capture + instantiate);
+//   * at most GRAPH_CACHE_SLOTS executables live at once, least-recently-used evicted with hipGraphExecDestroy;
+//   * the key carries the device ordinal and every device has its own capture stream.
+// Anything unexpected falls back to the plain launches.
 struct GraphKey {
     int kind;                 // 0 forward, 1 backward
+    int device;
     int64_t batch;
     int M, E, H, dtype, mask_mode, topo;
     bool operator==(const GraphKey& o) const {
-        return kind == o.kind && batch == o.batch && M == o.M && E == o.E && H == o.H && dtype == o.dtype &&
-               mask_mode == o.mask_mode && topo == o.topo;
+        return kind == o.kind && device == o.device && batch == o.batch && M == o.M && E == o.E && H == o.H &&
+               dtype == o.dtype && mask_mode == o.mask_mode && topo == o.topo;
     }
 };
 struct GraphSlot {
     GraphKey key;
     hipGraphExec_t exec;
+    uint64_t last_use;
 };
+struct GraphSighting {
+    GraphKey key;
+    int count;
+    uint64_t last_use;
+};
+constexpr int GRAPH_CACHE_SLOTS = 8;
+constexpr int GRAPH_SIGHTING_SLOTS = 32;
+constexpr int GRAPH_MIN_SIGHTINGS = 3;
+constexpr int MAX_DEVICES = 16;
 std::mutex g_graph_mu;
 std::vector<GraphSlot> g_graph_cache;
-thread_local hipStream_t t_capture_stream = nullptr;
+std::vector<GraphSighting> g_graph_seen;
+hipStream_t g_capture_stream[MAX_DEVICES] = {};
+uint64_t g_graph_clock = 0;
+
+// environment switches are read once per process (A/B timing and tests), never on the call path
+struct EnvSwitches {
+    int graph;          // AECF_GRAPH: -1 unset, 0 off, 1 on
+    bool no_ws;         // AECF_NO_WS: tiled kernels instead of the weight-stationary ones
+    int no_gate_fusion; // AECF_NO_GATE_FUSION
+    int no_fused;       // AECF_NO_FUSED: round-1 multi-kernel pipeline instead of the fused row kernels
+};
+const EnvSwitches& env_switches() {
+    static const EnvSwitches e = [] {
+        EnvSwitches v;
+        v.graph = getenv("AECF_GRAPH") ? atoi(getenv("AECF_GRAPH")) : -1;
+        v.no_ws = getenv("AECF_NO_WS") != nullptr;
+        v.no_gate_fusion = getenv("AECF_NO_GATE_FUSION") ? atoi(getenv("AECF_NO_GATE_FUSION")) : 0;
+        v.no_fused = getenv("AECF_NO_FUSED") ? atoi(getenv("AECF_NO_FUSED")) : 0;
+        return v;
+    }();
+    return e;
+}
+
+bool env_no_ws() { return env_switches().no_ws; }
+bool env_no_gate_fusion() { return env_switches().no_gate_fusion != 0; }
 
 // Measured (C2, same box, 3 x A/B): the graph form halves the HOST cost of a step (0.39 -> 0.20 ms) but the GPU runs the
 // large kernels ~2 % slower under it (0.632 vs 0.619 ms), so it is used where the host is the bound: calls whose
 // activations are small (B*M*E up to 2^25 elements; the configs[2] shard at 8192 rows per GPU goes 0.37 -> 0.27 ms).
-// AECF_GRAPH=0 / 1 forces it off / on (A/B timing and tests).
+// AECF_GRAPH=0 / 1 forces it off / on (A/B timing and tests; forced on also skips the sightings threshold).
 bool graphs_enabled(const aecf_pool_desc* d) {
-    static const int forced = getenv("AECF_GRAPH") ? atoi(getenv("AECF_GRAPH")) : -1;
+    const int forced = env_switches().graph;
     if (forced >= 0) return forced != 0;
     return (int64_t)d->batch * d->modalities * d->embed_dim <= ((int64_t)1 << 25);
 }
 
 // runs body(capture stream) as ONE executable graph on `user`; false = nothing was enqueued (the caller launches plainly)
 template <class F>
-bool run_as_graph(const GraphKey& key, hipStream_t user, F&& body, int* status) {
+bool run_as_graph(GraphKey key, hipStream_t user, F&& body, int* status) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(user, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
         return false;                                   // the caller is capturing: our launches join ITS graph
     }
-    if (!t_capture_stream && hipStreamCreateWithFlags(&t_capture_stream, hipStreamNonBlocking) != hipSuccess) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return false; }
+    key.device = dev;
+    std::lock_guard<std::mutex> lock(g_graph_mu);       // capture + update + launch of one call are one critical section
+    const uint64_t now = ++g_graph_clock;
+    GraphSlot* slot = nullptr;
+    for (auto& sl : g_graph_cache)
+        if (sl.key == key) { slot = &sl; break; }
+    if (!slot && env_switches().graph != 1) {           // not cached yet: count the sighting, stay on plain launches
+        GraphSighting* seen = nullptr;
+        for (auto& sg : g_graph_seen)
+            if (sg.key == key) { seen = &sg; break; }
+        if (!seen) {
+            if ((int)g_graph_seen.size() < GRAPH_SIGHTING_SLOTS) {
+                g_graph_seen.push_back(GraphSighting{key, 0, now});
+                seen = &g_graph_seen.back();
+            } else {                                    // recycle the least recently seen entry
+                seen = &g_graph_seen[0];
+                for (auto& sg : g_graph_seen)
+                    if (sg.last_use < seen->last_use) seen = &sg;
+                *seen = GraphSighting{key, 0, now};
+            }
+        }
+        seen->last_use = now;
+        if (++seen->count < GRAPH_MIN_SIGHTINGS) return false;
+    }
+    hipStream_t& cap = g_capture_stream[dev];
+    if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
-        t_capture_stream = nullptr;
+        cap = nullptr;
         return false;
     }
-    if (hipStreamBeginCapture(t_capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    const int rc = body(t_capture_stream);
+    const int rc = body(cap);
     hipGraph_t g = nullptr;
-    if (hipStreamEndCapture(t_capture_stream, &g) != hipSuccess || g == nullptr || rc != AECF_OK) {
+    if (hipStreamEndCapture(cap, &g) != hipSuccess || g == nullptr || rc != AECF_OK) {
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
         if (rc != AECF_OK) { *status = rc; return true; }      // a validation error: report it, nothing to launch
         return false;
     }
     bool ok = false;
-    {
-        std::lock_guard<std::mutex> lock(g_graph_mu);
-        GraphSlot* slot = nullptr;
-        for (auto& sl : g_graph_cache)
-            if (sl.key == key) { slot = &sl; break; }
-        if (slot) {
-            hipGraphExecUpdateResult res;
-            hipGraphNode_t bad = nullptr;
-            if (hipGraphExecUpdate(slot->exec, g, &bad, &res) != hipSuccess) {        // topology changed: rebuild
-                (void)hipGetLastError();
-                (void)hipGraphExecDestroy(slot->exec);
-                slot->exec = nullptr;
-                if (hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0) != hipSuccess) slot->exec = nullptr;
-            }
-        } else {
-            hipGraphExec_t ex = nullptr;
-            if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
-                g_graph_cache.push_back(GraphSlot{key, ex});
-                slot = &g_graph_cache.back();
-            }
+    if (slot) {
+        hipGraphExecUpdateResult res;
+        hipGraphNode_t bad = nullptr;
+        if (hipGraphExecUpdate(slot->exec, g, &bad, &res) != hipSuccess) {        // topology changed: rebuild
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(slot->exec);
+            slot->exec = nullptr;
+            if (hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0) != hipSuccess) slot->exec = nullptr;
         }
-        if (slot && slot->exec) ok = hipGraphLaunch(slot->exec, user) == hipSuccess;
-        if (slot && !slot->exec) {                      // could not be built: forget the slot
-            for (size_t i = 0; i < g_graph_cache.size(); ++i)
-                if (&g_graph_cache[i] == slot) { g_graph_cache.erase(g_graph_cache.begin() + i); break; }
+    } else {
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+            if ((int)g_graph_cache.size() >= GRAPH_CACHE_SLOTS) {                 // evict the least recently used
+                size_t lru = 0;
+                for (size_t i = 1; i < g_graph_cache.size(); ++i)
+                    if (g_graph_cache[i].last_use < g_graph_cache[lru].last_use) lru = i;
+                (void)hipGraphExecDestroy(g_graph_cache[lru].exec);
+                g_graph_cache.erase(g_graph_cache.begin() + lru);
+            }
+            g_graph_cache.push_back(GraphSlot{key, ex, now});
+            slot = &g_graph_cache.back();
         }
+    }
+    if (slot && slot->exec) {
+        slot->last_use = now;
+        ok = hipGraphLaunch(slot->exec, user) == hipSuccess;
+    }
+    if (slot && !slot->exec) {                      // could not be built: forget the slot
+        for (size_t i = 0; i < g_graph_cache.size(); ++i)
+            if (&g_graph_cache[i] == slot) { g_graph_cache.erase(g_graph_cache.begin() + i); break; }
     }
     (void)hipGraphDestroy(g);
     if (!ok) { (void)hipGetLastError(); return false; }
@@ -466,7 +540,7 @@ extern "C" {
 int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream) {
     hipStream_t user = (hipStream_t)stream;
     if (d && a && !a->stage_events && graphs_enabled(d)) {         // (the per-stage events need the plain launches)
-        const GraphKey key{0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
+        const GraphKey key{0, 0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
                            (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->key_padding_mask ? 4 : 0)};
         int status = AECF_OK;
         if (run_as_graph(key, user, [&](hipStream_t s) { return pool_forward_on(d, a, s); }, &status)) return status;
@@ -477,7 +551,7 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
 int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream) {
     hipStream_t user = (hipStream_t)stream;
     if (d && a && !a->stage_events && graphs_enabled(d)) {
-        const GraphKey key{1, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
+        const GraphKey key{1, 0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
                            (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->d_entropy ? 4 : 0) | (a->grad_dtype << 4)};
         int status = AECF_OK;
         if (run_as_graph(key, user, [&](hipStream_t s) { return pool_backward_on(d, a, s); }, &status)) return status;

@@ -79,7 +79,7 @@ class _PoolFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, q, w_in, b_in, w_out, b_out, kpm, uniforms, num_heads, mask_mode, min_active,
-                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None):
+                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None, casts=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)       # unused outputs arrive as None, not as zero tensors (fill + cast launches)
         B, M, E = x.shape
@@ -89,10 +89,13 @@ class _PoolFunction(torch.autograd.Function):
         _lib.check(lib.aecf_pool_check(ctypes.byref(desc)), "aecf_pool_check")
         xc = x.contiguous()
         qc = q.detach().reshape(E).to(dt).contiguous()
-        w_in_c = w_in.detach().to(dt).contiguous()
-        w_out_c = w_out.detach().to(dt).contiguous()
-        b_in_c = None if b_in is None else b_in.detach().to(dt).contiguous()
-        b_out_c = None if b_out is None else b_out.detach().to(dt).contiguous()
+        if casts is not None:                  # activation-dtype copies of master weights, cached by the module
+            w_in_c, b_in_c, w_out_c, b_out_c = casts
+        else:
+            w_in_c = w_in.detach().to(dt).contiguous()
+            w_out_c = w_out.detach().to(dt).contiguous()
+            b_in_c = None if b_in is None else b_in.detach().to(dt).contiguous()
+            b_out_c = None if b_out is None else b_out.detach().to(dt).contiguous()
         dev = x.device
         y = torch.empty(B, E, dtype=dt, device=dev)
         attn_w = torch.empty(B, M, dtype=torch.float32, device=dev)
@@ -185,7 +188,7 @@ class _PoolFunction(torch.autograd.Function):
                 db_in.to(bid) if (ctx.has_bias[0] and needs[3]) else None,
                 dw_out.to(wod) if needs[4] else None,
                 db_out.to(bod) if (ctx.has_bias[1] and needs[5]) else None,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 class _MaskFunction(torch.autograd.Function):
@@ -476,6 +479,26 @@ class MultimodalAttentionPool(nn.Module):
         self.curriculum_masking = curriculum_masking
         self.attention = nn.MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads, dropout=dropout,    # ref :399-407
                                                bias=bias, batch_first=batch_first, device=device, dtype=dtype)
+        self._cast_cache: Dict[str, Any] = {}
+
+    def _activation_dtype_params(self, dt: torch.dtype):
+        """Master weights kept in another dtype than the activations (float32 parameters, bf16 data): the kernels want
+        them in the activation dtype.  The copies are remade only when a parameter has changed (its autograd version or
+        storage moved), not on every forward -- 4E^2 elements and 3-4 cast launches per call otherwise."""
+        a = self.attention
+        out = []
+        for name, p in (("w_in", a.in_proj_weight), ("b_in", a.in_proj_bias), ("w_out", a.out_proj.weight),
+                        ("b_out", a.out_proj.bias)):
+            if p is None:
+                out.append(None)
+                continue
+            key = (p._version, p.data_ptr(), p.device, dt)
+            hit = self._cast_cache.get(name)
+            if hit is None or hit[0] != key:
+                hit = (key, p.detach().to(dt).contiguous())
+                self._cast_cache[name] = hit
+            out.append(hit[1])
+        return tuple(out)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: Optional[torch.Tensor] = None,
                 key_padding_mask: Optional[torch.Tensor] = None, attn_mask: Optional[torch.Tensor] = None,
@@ -577,7 +600,7 @@ class MultimodalAttentionPool(nn.Module):
             x, q_base, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, kpm, mask_u,
             self.num_heads, mask_mode, 1 if cm is None else int(cm.min_active),
             0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8,
-            False, tgt_value)
+            False, tgt_value, self._activation_dtype_params(x.dtype) if a.in_proj_weight.dtype != x.dtype else None)
 
         dt = x.dtype
         attn_output = y.unsqueeze(1) if self.batch_first else y.unsqueeze(0)          # [B,1,E] / [1,B,E]

@@ -9,14 +9,28 @@
  *
  * Conventions
  *  - plain C symbols, plain pointers and sizes, no C++/torch types.
- *  - the CALLER owns every buffer (including the workspace); the library never allocates,
- *    frees or retains device memory, never synchronises the stream and never throws.
- *  - every call only enqueues kernels on `stream` (a hipStream_t passed as void*).
+ *  - the CALLER owns every buffer (including the workspace); the library never allocates or
+ *    frees device memory, never retains a caller pointer past the call, never synchronises
+ *    the stream and never throws.
+ *  - every call only enqueues work on `stream` (a hipStream_t passed as void*): kernels, or -- for small
+ *    aecf_pool_forward / aecf_pool_backward calls whose shape keeps coming back -- one executable HIP graph of those
+ *    kernels (see "Library-owned state" below).
  *  - return value: AECF_OK (0) or a negative aecf_status.
- *  - dtype: AECF_BF16 or AECF_F32 for x / query / weights / y.  All statistics
- *    (attention weights, entropy, mask rate, saved probabilities) and all parameter
- *    gradients are float32.
- *  - re-entrant; no global mutable state.
+ *  - dtype: AECF_BF16 or AECF_F32 for x / query / weights / y.  All statistics (attention weights, entropy, mask rate,
+ *    saved probabilities) are float32 (optional copies in the activation dtype: aecf_pool_fwd_args.info_*).  Parameter
+ *    gradients are float32, or bf16 when aecf_pool_bwd_args.grad_dtype asks for it (bf16 parameters: the float32 batch
+ *    sums are rounded once, in the reduction kernel).
+ *  - thread-safe: any thread may call with any stream of the current device; calls that replay a graph are serialised
+ *    by one mutex.
+ *  Library-owned state (all host-side, bounded, process-lifetime):
+ *    * environment switches read once per process: AECF_GRAPH (0/1 forces graph replay off/on), AECF_NO_WS,
+ *      AECF_NO_GATE_FUSION, AECF_NO_WIDE_TN, AECF_NO_FUSED (A/B timing: route a shape through the fallback kernels);
+ *    * one non-blocking capture stream per device, created on first use;
+ *    * a cache of at most 8 hipGraphExec_t, least-recently-used evicted (hipGraphExecDestroy), keyed on
+ *      (forward/backward, device, B, M, E, H, dtype, mask mode, which optional pointers are set).  A shape is captured
+ *      and instantiated only from its 3rd sighting on, and only when B*M*E <= 2^25 (host-bound calls); larger calls and
+ *      first sightings are plain kernel launches.  A graph holds no caller memory: its kernel arguments are rewritten
+ *      (hipGraphExecUpdate) from the current call's pointers before every launch.
  */
 #ifndef AECF_HIP_H
 #define AECF_HIP_H

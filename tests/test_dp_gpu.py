@@ -55,7 +55,7 @@ def _run_shard(query, pool, x, dy, u, dev, scale):
     loss = ((out.float() * dy.to(dev).float()).sum() / B + 1e-2 * info["attention_weights"].float().pow(2).sum() / B
             + 0.0 * ent) * scale
     loss.backward()
-    return out.detach(), info["masked_attention_weights"].detach(), xs.grad
+    return out.detach(), info["masked_attention_weights"].detach(), xs.grad / scale    # (a power of two: exact)
 
 
 def _worker(rank, world, port, backend, dtype, q):

@@ -147,3 +147,31 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libaecf_hip.so")
     with pytest.raises(RuntimeError, match="HIP library not found"):
         _lib.load()
+
+
+def test_aecf_shim_is_the_drop_in_name():
+    """`import aecf` (the reference's package name, ref aecf/__init__.py:8-21) resolves to this implementation: same four
+    public names, same version, and the module path user code imports from."""
+    import aecf
+    import aecf.AECFLayer as L
+    assert sorted(aecf.__all__) == sorted(['CurriculumMasking', 'MultimodalAttentionPool', 'multimodal_attention_pool',
+                                           'create_fusion_pool'])
+    assert aecf.__version__ == "0.1.0"
+    for name in aecf.__all__:
+        assert getattr(aecf, name) is getattr(aecf_amd, name) is getattr(L, name)
+
+
+def test_uniforms_argument_is_public_and_validated():
+    """the mask uniforms are a public keyword of both forwards (no module-level hook)."""
+    import inspect
+    from aecf_amd import layer
+    assert not hasattr(layer, "_uniforms_override")
+    for fn in (aecf_amd.MultimodalAttentionPool.forward, aecf_amd.CurriculumMasking.forward):
+        ps = inspect.signature(fn).parameters
+        assert ps["uniforms"].kind is inspect.Parameter.KEYWORD_ONLY and ps["uniforms"].default is None
+        assert ps["generator"].kind is inspect.Parameter.KEYWORD_ONLY
+    # the reference's positional order is untouched (ref aecf/AECFLayer.py:409-418)
+    names = list(inspect.signature(aecf_amd.MultimodalAttentionPool.forward).parameters)
+    assert names[:8] == ["self", "query", "key", "value", "key_padding_mask", "attn_mask", "return_info", "use_checkpoint"]
+    with pytest.raises(ValueError):
+        layer._draw_uniforms((4, 1, 3), torch.device("cpu"), torch.zeros(5))

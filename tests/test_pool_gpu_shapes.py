@@ -157,3 +157,58 @@ def test_bf16_fallback_kernels_at_the_hot_path_shape(knobs):
         assert res["errs"][k] < 4e-3, (k, res["errs"][k])
     assert res["errs"]["dq"] < 6e-3
     assert res["agree"] > 0.99
+
+
+_GRAPH_SCRIPT = r"""
+import json, sys, torch
+sys.path.insert(0, {root!r})
+import aecf_amd
+dev = torch.device("cuda:0")
+torch.manual_seed(3)
+E, H, M = 128, 4, 3
+q, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=0.3, num_heads=H)
+pool = pool.to(dev, torch.bfloat16).train()
+q = torch.nn.Parameter(q.detach().to(dev, torch.bfloat16))
+g = torch.Generator(device=dev).manual_seed(5)
+# 50 steps queued back to back with DIFFERENT tensors and no synchronisation in between; 12 distinct batch sizes so that
+# the executable-graph cache (8 slots) also evicts and re-instantiates while launches are still queued
+sizes = [64 + 16 * (i % 12) for i in range(50)]
+xs = [torch.randn(b, M, E, device=dev, generator=g).to(torch.bfloat16).requires_grad_(True) for b in sizes]
+dys = [torch.randn(b, 1, E, device=dev, generator=g).to(torch.bfloat16) for b in sizes]
+us = [torch.rand(b, 1, M, device=dev, generator=g) for b in sizes]
+torch.cuda.synchronize()
+outs = []
+for x, dy, u in zip(xs, dys, us):
+    y, info = pool(q.expand(x.shape[0], -1, -1), x, return_info=True, uniforms=u)
+    y.backward(dy)
+    outs.append((y.detach(), info["masked_attention_weights"], x.grad))
+torch.cuda.synchronize()
+import hashlib
+h = hashlib.sha256()
+for y, m, dx in outs:
+    for t_ in (y, m, dx):
+        h.update(t_.float().cpu().numpy().tobytes())
+h.update(pool.attention.in_proj_weight.grad.float().cpu().numpy().tobytes())
+print("RESULT " + h.hexdigest())
+"""
+
+
+def test_graph_replay_back_to_back():
+    """hipGraphExecUpdate on a cached executable while earlier launches of it may still be queued relies on
+    arguments being snapshotted at launch.  50 unsynchronised forward+backward steps on different tensors (12 shapes over
+    an 8-slot cache: evictions included) must give bit-identical results with graph replay forced on -- with and without
+    HIP_FORCE_DEV_KERNARG -- and with plain launches."""
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    digests = {}
+    for name, knobs in (("plain", {"AECF_GRAPH": "0"}), ("graph", {"AECF_GRAPH": "1", "HIP_FORCE_DEV_KERNARG": "0"}),
+                        ("graph_devkernarg", {"AECF_GRAPH": "1", "HIP_FORCE_DEV_KERNARG": "1"}),
+                        ("default", {})):
+        env = dict(os.environ, **knobs)
+        out = subprocess.run([sys.executable, "-c", _GRAPH_SCRIPT.format(root=ROOT)], env=env, capture_output=True,
+                             text=True, timeout=280)
+        assert out.returncode == 0, (name, out.stderr[-2000:])
+        digests[name] = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]
+    assert len(set(digests.values())) == 1, digests
