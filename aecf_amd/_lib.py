@@ -13,7 +13,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaecf_hip.so")
 
-AECF_ABI_VERSION = 3
+AECF_ABI_VERSION = 4
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_FWD_STAGES = 4
@@ -97,6 +97,7 @@ _SYMBOLS = [
     ("aecf_pool_fwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_bwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_prep_bytes", c_size_t, [POINTER(PoolDesc)]),
+    ("aecf_pool_wants_saved_v", c_int, [POINTER(PoolDesc)]),
     ("aecf_pool_forward", c_int, [POINTER(PoolDesc), POINTER(PoolFwdArgs), c_void_p]),
     ("aecf_pool_backward", c_int, [POINTER(PoolDesc), POINTER(PoolBwdArgs), c_void_p]),
     ("aecf_curriculum_mask_forward", c_int,

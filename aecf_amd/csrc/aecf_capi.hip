@@ -17,8 +17,9 @@ using namespace aecf;
 namespace {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-bool env_no_ws();              // AECF_NO_WS / AECF_NO_GATE_FUSION, read once per process (defined with the graph cache)
+bool env_no_ws();              // AECF_NO_WS / AECF_NO_GATE_FUSION / AECF_FUSED_FWD, read once per process (defined with the graph cache)
 bool env_no_gate_fusion();
+bool env_fused_fwd();
 inline int esize(int dtype) { return dtype == AECF_BF16 ? 2 : 4; }
 
 struct FwdWs {
@@ -63,7 +64,7 @@ PrepWs prep_layout(const aecf_pool_desc* d) {
 struct BwdWs {
     PrepWs prep;
     size_t dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, dq_part, total;
-    int splits, u_splits;
+    int splits, u_splits, u_splits_cap;
     int64_t rows_per_split, u_rows_per_split;
 };
 BwdWs bwd_layout(const aecf_pool_desc* d) {
@@ -98,7 +99,8 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     w.slab_v = off; off = align_up(off + (size_t)S * E * E * 4);
     w.cs_o = off;   off = align_up(off + (size_t)S * E * 4);
     w.cs_v = off;   off = align_up(off + (size_t)S * E * 4);
-    w.u_slab = off; off = align_up(off + (size_t)w.u_splits * HPAD * E * 4);
+    w.u_splits_cap = w.u_splits > 256 ? w.u_splits : 256;            // the head-split kernel writes up to 256 slabs
+    w.u_slab = off; off = align_up(off + (size_t)w.u_splits_cap * HPAD * E * 4);
     w.u = off;      off = align_up(off + HPAD * E * 4);
     w.dqp = off;    off = align_up(off + E * 4);
     w.dq_part = off; off = align_up(off + (E / 16) * E * 4);
@@ -176,6 +178,16 @@ size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d) {
     return bwd_layout(d).total;
 }
 
+int aecf_pool_wants_saved_v(const aecf_pool_desc* d) {
+    if (aecf_pool_check(d) != AECF_OK) return 0;
+    if (d->dtype == AECF_BF16 && !env_no_ws()) {
+        BwdGArgs g;
+        g.B = d->batch; g.M = d->modalities; g.E = d->embed_dim; g.H = d->num_heads; g.hd = d->embed_dim / d->num_heads;
+        if (dsu_ws_chunks(g) > 0) return 0;        // the score gradient comes from x (dsu_ws_kernel): nothing to save
+    }
+    return 1;
+}
+
 size_t aecf_pool_prep_bytes(const aecf_pool_desc* d) {
     if (aecf_pool_check(d) != AECF_OK) return 0;
     return prep_layout(d).total;
@@ -241,6 +253,18 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
     v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = 0; v.v_out = a->saved_v;
     if (frag) v.w_frag = ws + L.wv_frag;
+    if (env_fused_fwd() && row_fwd_supported(d->dtype, E, M, H)) {
+        // ONE kernel from x to y: scores, softmax, statistics, value projection, pooling, out-projection (aecf_row_fwd.hip)
+        GemmNtArgs yo;
+        yo.a = o; yo.w = a->w_out; yo.bias = a->b_out; yo.c = a->y; yo.probs = nullptr; yo.R = d->batch; yo.N = E; yo.K = E;
+        yo.lda = E; yo.M = 1; yo.H = H; yo.hd = hd; yo.pooled = 0; yo.out_f32 = 0; yo.v_out = nullptr;
+        v.c = a->saved_o;                                  // kept only when the caller wants it (backward)
+        mark(ev, 2, s);
+        launch_row_fwd(g, v, yo, s);
+        mark(ev, 3, s);
+        mark(ev, 4, s);
+        return launch_status();
+    }
     // bf16, shapes of the weight-stationary kernel, M <= 3: the scores are formed inside the value projection (one pass
     // over x for both) and the per-sample statistics follow from the saved weights; otherwise the gate kernel runs first
     bool fuse_gate = d->dtype == AECF_BF16 && M <= 3 && !env_no_gate_fusion() && !env_no_ws();   // (A/B timing switches)
@@ -325,8 +349,13 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     g2.d_entropy = a->d_entropy; g2.attn_w = a->attn_w; g2.dsbuf = dsbuf; g2.a_f32 = a_f32; g2.dx = a->dx;
     g2.B = B; g2.M = M; g2.E = E; g2.H = H; g2.hd = hd; g2.log_M = (float)log((double)M);
     if (frag) g2.wvt_frag = pb + P.wvt_frag;
-    if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
-        launch_bwd_g(d->dtype, g2, false, s);      // no saved V (or unsupported head size): recompute W_v^T do per head
+    // score gradient.  bf16 shapes of the head-split weight-stationary kernel: ds AND u = ds^T x in one pass over (do, x),
+    // nothing saved by the forward; otherwise from the saved V (memory-bound dot), else by recomputing W_v^T do per head
+    int dsu_chunks = 0;
+    if (d->dtype == AECF_BF16 && !env_no_ws() && dsu_ws_chunks(g2) > 0 && dsu_ws_chunks(g2) <= L.u_splits_cap)
+        dsu_chunks = launch_dsu_ws(g2, (float*)(ws + L.u_slab), s);
+    else if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
+        launch_bwd_g(d->dtype, g2, false, s);
     mark(ev, 4, s);
     if (!(d->dtype == AECF_BF16 && launch_dx_ws(g2, s))) launch_bwd_g(d->dtype, g2, true, s);
     mark(ev, 5, s);
@@ -340,13 +369,15 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     t2.parts = 1;
     launch_gemm_tn(d->dtype, t2, s);
     mark(ev, 6, s);
-    t2.parts = 2;
-    launch_gemm_tn(d->dtype, t2, s);
+    if (!dsu_chunks) {
+        t2.parts = 2;
+        launch_gemm_tn(d->dtype, t2, s);
+    }
     mark(ev, 7, s);
 
     ReduceSegs rs;
     for (int i = 0; i < ReduceSegs::N; ++i) rs.splits[i] = L.splits;
-    rs.splits[4] = L.u_splits;
+    rs.splits[4] = dsu_chunks ? dsu_chunks : L.u_splits;
     const int gb = a->grad_dtype == AECF_BF16 ? 1 : 0;
     const size_t gsz = gb ? 2 : 4;                                    // bytes per parameter-gradient element
     for (int i = 0; i < ReduceSegs::N; ++i) rs.dst_bf16[i] = gb;
@@ -416,7 +447,8 @@ struct EnvSwitches {
     int graph;          // AECF_GRAPH: -1 unset, 0 off, 1 on
     bool no_ws;         // AECF_NO_WS: tiled kernels instead of the weight-stationary ones
     int no_gate_fusion; // AECF_NO_GATE_FUSION
-    int no_fused;       // AECF_NO_FUSED: round-1 multi-kernel pipeline instead of the fused row kernels
+    int fused_fwd;      // AECF_FUSED_FWD=1: the one-kernel row-stationary forward (aecf_row_fwd.hip) instead of the
+                        // weight-stationary pair (measured slower at C2: DESIGN.md section 5)
 };
 const EnvSwitches& env_switches() {
     static const EnvSwitches e = [] {
@@ -424,7 +456,7 @@ const EnvSwitches& env_switches() {
         v.graph = getenv("AECF_GRAPH") ? atoi(getenv("AECF_GRAPH")) : -1;
         v.no_ws = getenv("AECF_NO_WS") != nullptr;
         v.no_gate_fusion = getenv("AECF_NO_GATE_FUSION") ? atoi(getenv("AECF_NO_GATE_FUSION")) : 0;
-        v.no_fused = getenv("AECF_NO_FUSED") ? atoi(getenv("AECF_NO_FUSED")) : 0;
+        v.fused_fwd = getenv("AECF_FUSED_FWD") ? atoi(getenv("AECF_FUSED_FWD")) : 0;
         return v;
     }();
     return e;
@@ -432,6 +464,7 @@ const EnvSwitches& env_switches() {
 
 bool env_no_ws() { return env_switches().no_ws; }
 bool env_no_gate_fusion() { return env_switches().no_gate_fusion != 0; }
+bool env_fused_fwd() { return env_switches().fused_fwd != 0; }
 
 // Measured (C2, same box, 3 x A/B): the graph form halves the HOST cost of a step (0.39 -> 0.20 ms) but the GPU runs the
 // large kernels ~2 % slower under it (0.632 vs 0.619 ms), so it is used where the host is the bound: calls whose

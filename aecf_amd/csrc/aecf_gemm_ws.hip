@@ -18,6 +18,8 @@
 //                softmax weight is a per-lane scalar and o is a sum over the 4 lanes of a quad (two xor shuffles)
 // One barrier per step; LDS tile rows are K*2 bytes with the 16-byte chunk index XOR-ed with the MFMA column index
 // (bank-conflict-free ds_read_b128; the DMA destination is lane-linear, so the XOR is applied to the source address).
+#include <stdlib.h>
+
 #include "aecf_kernels.h"
 #include "aecf_tile.h"
 
@@ -49,6 +51,35 @@ __device__ __forceinline__ void ws_dma_rows(const char* __restrict__ src, unsign
     }
 }
 
+// the same copy issued through inline asm: invisible to hipcc's waitcnt insertion, which otherwise puts s_waitcnt vmcnt(0)
+// in front of the first LDS read that follows a global_load_lds it can see whenever ordinary loads are in flight as well
+// (the copy would then be serialised with the compute of the step it is meant to fly behind).  The caller retires it with
+// its own s_waitcnt vmcnt(0).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <int KT, int NROWS, int KEYDIV>
+__device__ __forceinline__ void ws_dma_rows_asm(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid, char* lds) {
+    constexpr int CPR = 4 * KT;
+    constexpr int TOTAL = NROWS * CPR;
+    constexpr int NI = (TOTAL + 511) / 512;
+    static_assert(TOTAL % 64 == 0, "whole wave-instructions");
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (wbase + 512 * i < TOTAL) {                // wave-uniform
+            const int c = threadIdx.x + 512 * i;
+            const int row = c / CPR, p = c - row * CPR;
+            const int rowc = row < rows_valid ? row : rows_valid - 1;
+            const int key = (row / KEYDIV) & 15;
+            const unsigned int voff = (unsigned)rowc * ld_bytes + (unsigned)((p ^ key) << 4);
+            const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(lds + (wbase + 512 * i) * 16);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst)
+                         : "memory", "m0");
+        }
+    }
+}
+#pragma clang diagnostic pop
+
 // GATE (VPROJ only): the softmax weights are PRODUCED here instead of read -- scores x . A[h] against the folded key
 // matrix (bf16 hi/lo split), one more use of the tile that is already in LDS, so the separate gate kernel and its pass
 // over x disappear.  Each wave takes KG = KT/8 K-steps of the score product for all 16 heads x 16 samples x M
@@ -69,6 +100,17 @@ __device__ __forceinline__ void store_cols(unsigned short* dst, const float* v) 
     } else {
         *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
+}
+
+// MFMA A/B operand of 8 consecutive ROWS (the K index) at one column per lane, from a row-major LDS tile, by two
+// transposed reads (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block, lane i receives column i)
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
+__device__ __forceinline__ u32x4 tr_frag16(const char* tile, int addr_lo, int addr_hi) {
+    const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(tile + addr_lo));
+    const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(tile + addr_hi));
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l[0], l[1], h[0], h[1]};
 }
 
 // CT = column tiles (of 16) per wave: 2 for K <= 512 (32 columns x K weights = up to 128 VGPRs, a block owns 256 columns),
@@ -558,6 +600,291 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Score gradient AND the key-side batch reduction from x, on the same engine -- no saved V, no separate pass over x:
+//     P_h[b, k]  = sum_{j in head h} do[b, j] W_v[j, k]                       (as in dx_ws2, MFMA)
+//     da[b,h,m]  = P_h[b, :] . x[b, m, :]            (= do_h . V_h[b,m] up to a term that cancels in the softmax backward)
+//     ds[b,h,:]  = a (dp - sum_m a dp),  dp = da + dwbar/H                     (dscore_v_kernel's arithmetic)
+//     u[h, k]   += sum_{b,m} ds[b,h,m] x[b,m,k]                                (MFMA on TRANSPOSED reads of the x tile)
+// The split over blocks is by HEADS, not by output columns: a block owns JB = 32 KJ columns j of do (whole heads) and ALL
+// E columns k, so the dot over k is complete inside the block (no cross-block reduction) and ds is final when the
+// u product needs it.  Resident weights: W_v^T rows k = 16 NCT per wave, K = the block's JB columns (E = 512, JB = 256:
+// 128 registers, as everywhere on this engine).  Per 16-sample step the x tile (16 M rows x E, LDS-DMA, two buffers) is
+// used three times without leaving the CU: as the vector operand of the dot, and -- read column-wise with
+// ds_read_b64_tr_b16 -- as the MFMA A operand of u^T = x^T ds (ds split hi/lo bf16).  HBM: do once, x once (the second
+// head group of a row chunk finds the rows in its XCD's L2), ds written (tiny); the forward no longer stores V.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ float dot2_bf16(unsigned int a, unsigned int b, float c) {     // v_dot2c_f32_bf16
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+template <int KT, int KJ, int HK, int M_, bool PKDOT>
+__global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __restrict__ u_slab, int rows_per_block, int nchunk) {
+    using X = Tr<BF16>;
+    constexpr int E = 32 * KT, JB = 32 * KJ, NCT = KT / 4;        // a wave owns E / 8 = 16 NCT columns k
+    constexpr int HBL = KJ / HK;                                  // heads per block
+    constexpr int ROWX = 2 * E, ROWD = 2 * JB;
+    constexpr int XROWS = 16 * M_;                                // x tile rows (b, m)
+    constexpr int KU = (XROWS + 31) / 32;                         // MFMA K-steps of the u product (K = x tile row)
+    constexpr int ZROWS = 32 * KU - XROWS;                        // K padding: rows of a shared all-zero page
+    constexpr int XT = XROWS * ROWX, DT = 16 * ROWD;
+    constexpr int HM = HBL * M_;
+    constexpr int NPART = 32;                                     // partial dots per (sample, head, m): 8 waves x 4 lane groups
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xb = smem;                                              // [2][16 M][E] x rows (b, m), 16-byte chunk ^ sample
+    char* zp = smem + 2 * XT;                                     // [ZROWS][E] zeros
+    char* db = zp + ZROWS * ROWX;                                 // [2][16][JB] do rows, chunk ^ row
+    float* part = reinterpret_cast<float*>(db + 2 * DT);          // [32][HM][16 samples]
+    unsigned short* dsh = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(part) + NPART * 16 * HM * 4);   // [16][64] bf16 hi
+    unsigned short* dsl = dsh + 16 * 64;                                                                            // [16][64] bf16 lo
+
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const int H = p.H;
+    unsigned int chunk_u, group_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(E / JB), chunk_u, group_u)) return;
+    const int jbase = (int)group_u * JB, hbase = jbase / (32 * HK);
+    const int ncol0 = 16 * NCT * w;
+    const int64_t o_beg = (int64_t)chunk_u * rows_per_block;
+    const int64_t o_end = (o_beg + rows_per_block) < p.B ? (o_beg + rows_per_block) : p.B;
+    if (o_beg >= o_end) return;
+
+    const char* dsrc = reinterpret_cast<const char*>(p.dobuf) + (int64_t)jbase * 2;
+    const char* xsrc = reinterpret_cast<const char*>(p.x);
+    auto issue = [&](int64_t o0, int buf) {
+        const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
+        ws_dma_rows_asm<KT, 16 * M_, M_>(xsrc + o0 * M_ * (int64_t)ROWX, (unsigned)ROWX, ov * M_, xb + buf * XT);
+        ws_dma_rows_asm<KJ, 16, 1>(dsrc + o0 * (int64_t)ROWX, (unsigned)ROWX, ov, db + buf * DT);
+    };
+    // what the DMA never writes and the MFMAs still read: the zero page, the ds operand arrays
+    for (int i = threadIdx.x; i < ZROWS * ROWX / 16; i += 512) reinterpret_cast<u32x4*>(zp)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < 2 * 16 * 64 / 2; i += 512) reinterpret_cast<unsigned int*>(dsh)[i] = 0u;
+    issue(o_beg, 0);
+
+    // ---- resident weights: A operand row r16 of column tile ct <-> k = ncol0 + 16 ct + r16, K = j
+    const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.wvt);
+    u32x4 wreg[KJ][NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const unsigned short* wr = wsrc + (int64_t)(ncol0 + 16 * ct + r16) * E + jbase + 8 * lg;
+#pragma unroll
+        for (int ks = 0; ks < KJ; ++ks) wreg[ks][ct] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
+    }
+    int daddr[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) daddr[v] = r16 * ROWD + ((((4 * v) + lg) ^ r16) << 4);
+    // the 8-byte piece of x row (r16, m = 0) that holds columns ncol0 + 4 lg .. + 3 of column tile 0; tile ct adds
+    // 2 ct to the chunk index BEFORE the xor with the sample, which (2 ct < 8, ncol0 / 8 a multiple of 8) is an xor of the
+    // byte offset with 32 ct
+    const int xaddr0 = r16 * M_ * ROWX + (((((ncol0 >> 3) + (lg >> 1))) ^ r16) << 4) + 8 * (lg & 1);
+    // transposed-read addresses of the u product (constant over the steps): K-step ks, rows 32 ks + 8 lg + q (+ 4),
+    // columns of tile 0; rows past the tile come from the zero page.  Relative to the x buffer / to smem for the zero page.
+    const int q = r16 >> 2, pp = r16 & 3;
+    int ua[KU][2];
+    bool uz[KU];
+#pragma unroll
+    for (int ks = 0; ks < KU; ++ks) {
+        const int row0 = 32 * ks + 8 * lg;
+        uz[ks] = row0 >= XROWS;                                   // (8-row groups never straddle the end: XROWS % 16 == 0)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int row = row0 + 4 * hh + q;
+            const int key = uz[ks] ? 0 : (row / M_) & 15;
+            const int ch = ((ncol0 >> 3) + (pp >> 1)) ^ key;
+            ua[ks][hh] = (uz[ks] ? (int)(zp - smem) + (row - XROWS) * ROWX : row * ROWX) + (ch << 4) + 8 * (pp & 1);
+        }
+    }
+
+    // ds threads: one wave per local head, lane = 16 m + sample (lane groups m >= M_ idle): the partial dots of a lane's
+    // (sample, m) are contiguous over the lanes (conflict-free LDS reads), the sum over m is a lane-group reduction
+    const int ds_s = lane & 15, ds_hh = w, ds_m = lg;
+    const bool ds_thread = w < HBL && ds_m < M_;
+    const float invH = 1.0f / (float)H;
+    // softmax weight and upstream weight gradient of a step, fetched one step ahead by inline-asm loads (see
+    // ws_dma_rows_asm: an ordinary load here would serialise the LDS-DMA with the compute); retired by the step's
+    // s_waitcnt vmcnt(0)
+    auto load_stats = [&](int64_t o0, float& pmv, float& dwb) {
+        int64_t b = o0 + ds_s;
+        b = b < o_end ? b : o_end - 1;
+        const float* pp_ = p.probs + (b * H + hbase + ds_hh) * M_ + (ds_m < M_ ? ds_m : 0);
+        const float* dw_ = p.d_attn_w ? p.d_attn_w + b * M_ + (ds_m < M_ ? ds_m : 0) : pp_;
+        if (w < HBL) {                                             // wave-uniform
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pmv) : "v"(pp_) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dwb) : "v"(dw_) : "memory");
+        }
+    };
+
+    f32x4 uacc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) uacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float pmv = 0.f, dwb = 0.f, pmv_n = 0.f, dwb_n = 0.f;
+    // the weights are USED here, so that hipcc retires their loads now: left to the first MFMA it would put counted
+    // s_waitcnt vmcnt(N) inside the loop, which (the inline-asm copies are invisible to its count) would wait for the
+    // copy issued at the top of every step
+#pragma unroll
+    for (int ks = 0; ks < KJ; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) asm volatile("" : "+v"(wreg[ks][ct]));
+    load_stats(o_beg, pmv, dwb);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int cur = 0;
+    for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
+        __builtin_amdgcn_s_barrier();                              // this step's tiles visible; the other buffers free
+        if (o0 + 16 < o_end) {
+            issue(o0 + 16, cur ^ 1);
+            load_stats(o0 + 16, pmv_n, dwb_n);
+        }
+        const char* tb = db + cur * DT;
+        const char* tx = xb + cur * XT;
+        // heads in groups of HG: P_h by MFMA, then the dot with this lane's x values (8-byte LDS reads at a per-tile base +
+        // an immediate; one read and one unpack serve the HG heads of the group).  Every lane writes its partial (16 NCT
+        // columns of one sample) to part[wave, lane group][head, m][sample]; the ds threads add the 32 of them.
+        constexpr int HG = (HBL % 2 == 0 && !PKDOT) ? 2 : 1;
+        int xa[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) xa[ct] = cur * XT + (xaddr0 ^ (32 * ct));
+        float* pw = part + (w * 4 + lg) * (HM * 16) + r16;
+#pragma unroll
+        for (int h0 = 0; h0 < HBL; h0 += HG) {
+            f32x4 P[HG][NCT];
+#pragma unroll
+            for (int g = 0; g < HG; ++g) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) P[g][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kl = 0; kl < HK; ++kl) {
+                    const int ks = (h0 + g) * HK + kl;
+                    const u32x4 bf = *reinterpret_cast<const u32x4*>(tb + daddr[ks & 3] + (ks >> 2) * 256);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) P[g][ct] = X::mma(wreg[ks][ct], bf, P[g][ct]);
+                }
+            }
+            unsigned int pk[HG][NCT][2];
+            if (PKDOT) {
+#pragma unroll
+                for (int g = 0; g < HG; ++g)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        pk[g][ct][0] = pack_bf16x2(P[g][ct][0], P[g][ct][1]);
+                        pk[g][ct][1] = pack_bf16x2(P[g][ct][2], P[g][ct][3]);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                float a[HG];
+#pragma unroll
+                for (int g = 0; g < HG; ++g) a[g] = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const u32x2 xv = *reinterpret_cast<const u32x2*>(xb + xa[ct] + m * ROWX);
+                    if (PKDOT) {
+#pragma unroll
+                        for (int g = 0; g < HG; ++g) {
+                            a[g] = dot2_bf16(pk[g][ct][0], xv[0], a[g]);
+                            a[g] = dot2_bf16(pk[g][ct][1], xv[1], a[g]);
+                        }
+                    } else {
+                        const float x0 = __uint_as_float(xv[0] << 16), x1 = __uint_as_float(xv[0] & 0xffff0000u);
+                        const float x2 = __uint_as_float(xv[1] << 16), x3 = __uint_as_float(xv[1] & 0xffff0000u);
+#pragma unroll
+                        for (int g = 0; g < HG; ++g) {
+                            a[g] = fmaf(P[g][ct][0], x0, a[g]);
+                            a[g] = fmaf(P[g][ct][1], x1, a[g]);
+                            a[g] = fmaf(P[g][ct][2], x2, a[g]);
+                            a[g] = fmaf(P[g][ct][3], x3, a[g]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < HG; ++g) pw[((h0 + g) * M_ + m) * 16] = a[g];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" : "+v"(pmv), "+v"(dwb));
+        if (w < HBL) {                                             // whole waves: the lane-group sum below needs every lane
+            float da = 0.f;
+            if (ds_m < M_) {
+                const float* pr = part + (ds_hh * M_ + ds_m) * 16 + ds_s;
+#pragma unroll
+                for (int i = 0; i < NPART; ++i) da += pr[i * (HM * 16)];                 // fixed order
+            }
+            float dw = p.d_attn_w ? dwb : 0.f;
+            if (p.d_entropy && ds_m < M_) {                        // eval mode: the entropy keeps its graph (ref :150-156)
+                int64_t be = o0 + ds_s;
+                be = be < o_end ? be : o_end - 1;
+                float hsum = 0.f;
+#pragma unroll
+                for (int m = 0; m < M_; ++m) hsum -= xlogx(p.attn_w[be * M_ + m]);
+                const bool live = (hsum >= 0.f) && (hsum <= p.log_M);
+                dw += live ? -(logf(p.attn_w[be * M_ + ds_m]) + 1.0f) * p.d_entropy[be] : 0.f;
+            }
+            const float dp = da + dw * invH;
+            const float dot = reduce_lg((ds_m < M_) ? pmv * dp : 0.f);     // over the M modalities of (sample, head)
+            const int64_t b = o0 + ds_s;
+            if (ds_m < M_) {
+                const float d = (b < o_end) ? pmv * (dp - dot) : 0.f;
+                if (b < o_end) p.dsbuf[(b * H + hbase + ds_hh) * M_ + ds_m] = d;
+                const unsigned short hi = X::from_f32(d);
+                dsh[ds_hh * 64 + ds_s * M_ + ds_m] = hi;
+                dsl[ds_hh * 64 + ds_s * M_ + ds_m] = X::from_f32(d - X::to_f32(hi));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // u^T[k, h] += x^T[k, (b,m)] ds[(b,m), h]:  A operand by transposed reads of the x tile (rows = K index)
+#pragma unroll
+        for (int ks = 0; ks < KU; ++ks) {
+            const u32x4 bh = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dsh) + (r16 * 64 + 32 * ks + 8 * lg) * 2);
+            const u32x4 bl = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dsl) + (r16 * 64 + 32 * ks + 8 * lg) * 2);
+            const char* base = uz[ks] ? smem : tx;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const u32x4 af = tr_frag16(base, ua[ks][0] ^ (32 * ct), ua[ks][1] ^ (32 * ct));
+                uacc[ct] = X::mma(af, bh, uacc[ct]);
+                uacc[ct] = X::mma(af, bl, uacc[ct]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tiles and statistics landed (a whole step to do so)
+        asm volatile("" : "+v"(pmv_n), "+v"(dwb_n));
+        pmv = pmv_n; dwb = dwb_n;
+    }
+    // u slab of this row chunk: rows = the block's heads, lane (lg, r16 = local head) holds k = ncol0 + 16 ct + 4 lg .. + 3
+    if (r16 < HBL) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+            *reinterpret_cast<f32x4*>(u_slab + ((int64_t)chunk_u * H + hbase + r16) * E + ncol0 + 16 * ct + 4 * lg) = uacc[ct];
+    }
+}
+
+template <int KT, int KJ, int HK, int M_>
+int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
+    constexpr int E = 32 * KT, JB = 32 * KJ, HBL = KJ / HK;
+    constexpr int XROWS = 16 * M_, ZROWS = 32 * ((XROWS + 31) / 32) - XROWS;
+    const size_t smem = (size_t)(2 * XROWS + ZROWS) * 2 * E + (size_t)2 * 16 * 2 * JB + (size_t)32 * 16 * HBL * M_ * 4 +
+                        (size_t)2 * 16 * 64 * 2;
+    const int groups = E / JB;
+    int64_t chunks = 256 / groups;
+    if (chunks < 1) chunks = 1;
+    int64_t rpb = (a.B + chunks - 1) / chunks;
+    rpb = (rpb + 15) / 16 * 16;
+    const int64_t nchunk = (a.B + rpb - 1) / rpb;
+    dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
+    static const int pkdot = getenv("AECF_DSU_PKDOT") ? atoi(getenv("AECF_DSU_PKDOT")) : 0;     // A/B: bf16-rounded P in the dot
+    if (pkdot) {
+        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
+    } else {
+        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
+    }
+    return (int)nchunk;
+}
+
 template <int KT, int HK, int M_>
 void launch_dx2(const BwdGArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
@@ -677,6 +1004,52 @@ void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s) {
     } else {
         launch_kt<WS_PLAIN, 1, false>(a, s);
     }
+}
+
+// score gradient + key-side batch reduction from x (no saved V); returns the number of u slabs written (row chunks), or 0
+// when the shape is not taken (caller falls back to dscore_v / bwd_g + u_stream)
+int dsu_ws_chunks(const BwdGArgs& a) {
+    if (a.M < 1 || a.M > 4 || a.hd % 32 != 0 || a.E != a.H * a.hd) return 0;
+    if (a.E != 256 && a.E != 512) return 0;
+    const int jb = 256;
+    if (jb % a.hd != 0) return 0;
+    const int hk = a.hd / 32;
+    if (hk != 1 && hk != 2 && hk != 4 && hk != 8) return 0;
+    {   // LDS: two x tiles + K-padding page + two do tiles + partial dots + ds operand arrays
+        const int xrows = 16 * a.M, zrows = 32 * ((xrows + 31) / 32) - xrows, hbl = jb / a.hd;
+        const size_t smem = (size_t)(2 * xrows + zrows) * 2 * a.E + (size_t)2 * 16 * 2 * jb + (size_t)32 * 16 * hbl * a.M * 4 + 4096;
+        if (smem > 160 * 1024) return 0;
+    }
+    const int groups = a.E / jb;
+    int64_t chunks = 256 / groups;
+    int64_t rpb = (a.B + chunks - 1) / chunks;
+    rpb = (rpb + 15) / 16 * 16;
+    return (int)((a.B + rpb - 1) / rpb);
+}
+
+template <int KT, int HK>
+static int launch_dsu_m(const BwdGArgs& a, float* u_slab, hipStream_t s) {
+    switch (a.M) {
+        case 1: return launch_dsu_t<KT, 8, HK, 1>(a, u_slab, s);
+        case 2: return launch_dsu_t<KT, 8, HK, 2>(a, u_slab, s);
+        case 3: return launch_dsu_t<KT, 8, HK, 3>(a, u_slab, s);
+        default: return launch_dsu_t<KT, 8, HK, 4>(a, u_slab, s);
+    }
+}
+
+int launch_dsu_ws(const BwdGArgs& a, float* u_slab, hipStream_t s) {
+    if (dsu_ws_chunks(a) == 0) return 0;
+    const int hk = a.hd / 32;
+#define DSU_CASE(KT_)                                                   \
+    switch (hk) {                                                       \
+        case 1: return launch_dsu_m<KT_, 1>(a, u_slab, s);              \
+        case 2: return launch_dsu_m<KT_, 2>(a, u_slab, s);              \
+        case 4: return launch_dsu_m<KT_, 4>(a, u_slab, s);              \
+        default: return launch_dsu_m<KT_, 8>(a, u_slab, s);             \
+    }
+    if (a.E == 256) { DSU_CASE(8) }
+    DSU_CASE(16)
+#undef DSU_CASE
 }
 
 // dx through the weight-stationary engine (bf16); false = shape not taken (caller uses launch_bwd_g(dx = true))

@@ -85,6 +85,11 @@ void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s);   // pooled ==
 bool gemm_ws_supported(const GemmNtArgs& a);                          // weight-stationary streaming form (bf16)
 void launch_gemm_ws(const GemmNtArgs& a, hipStream_t s);
 
+// fused forward (aecf_row_fwd.hip): prep products in g (a_hi / a_lo), value projection operands in v (w, bias, c = saved o,
+// v_out = saved V or null), out-projection operands in y (w, bias, c = y)
+bool row_fwd_supported(int dtype, int E, int M, int H);
+void launch_row_fwd(const GateArgs& g, const GemmNtArgs& v, const GemmNtArgs& y, hipStream_t s);
+
 // ---------------- backward ----------------
 // g_h[b] = W_v,h^T do_h[b] kernels (aecf_bwd_g.hip):
 //   dx == false: da[b,h,m] = g_h[b] . x[b,m] -> ds = softmax-backward(da + dwbar/H) -> dsbuf [B,H,M]
@@ -109,7 +114,11 @@ void launch_bwd_g(int dtype, const BwdGArgs& a, bool dx, hipStream_t s);
 // score gradient from the saved value projections: da[b,h,m] = do_h[b] . V_h[b,m]  (memory-bound, one wave per sample)
 // returns false when the head size is not supported by this kernel (caller falls back to launch_bwd_g(dx = false))
 bool launch_dscore_v(int dtype, const BwdGArgs& a, const void* saved_v, hipStream_t s);
-bool launch_dx_ws(const BwdGArgs& a, hipStream_t s);        // bf16 dx on the weight-stationary engine (aecf_gemm_ws.hip)
+bool launch_dx_ws(const BwdGArgs& a, hipStream_t s);
+// score gradient + u = ds^T x straight from x (no saved V), bf16 weight-stationary engine with a head split
+// (aecf_gemm_ws.hip: dsu_ws_kernel).  dsu_ws_chunks: number of [H, E] u slabs it will write (0 = shape not taken)
+int dsu_ws_chunks(const BwdGArgs& a);
+int launch_dsu_ws(const BwdGArgs& a, float* u_slab, hipStream_t s);        // bf16 dx on the weight-stationary engine (aecf_gemm_ws.hip)
 
 // out[split][j][k] = sum_{b in split} lhs[b][j] * rhs(b,k)        (f32 partial slabs, deterministic)
 //   pooled == 0: rhs(b,k) = rhs[b*E + k]

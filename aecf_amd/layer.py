@@ -103,7 +103,8 @@ class _PoolFunction(torch.autograd.Function):
         saved_o = torch.empty(B, E, dtype=dt, device=dev)
         # per-modality value projections, kept only when a backward will follow (B*M*E elements)
         need_bwd = any(t is not None and t.requires_grad for t in (x, q, w_in, b_in, w_out, b_out))
-        saved_v = torch.empty(B, M, E, dtype=dt, device=dev) if need_bwd else None
+        saved_v = (torch.empty(B, M, E, dtype=dt, device=dev)
+                   if (need_bwd and lib.aecf_pool_wants_saved_v(ctypes.byref(desc))) else None)
         # what the backward derives from the parameters alone is produced by the forward's preparation launch
         saved_prep = (torch.empty(lib.aecf_pool_prep_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
                       if (need_bwd and _SHARE_PREP) else None)

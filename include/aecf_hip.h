@@ -24,7 +24,8 @@
  *    by one mutex.
  *  Library-owned state (all host-side, bounded, process-lifetime):
  *    * environment switches read once per process: AECF_GRAPH (0/1 forces graph replay off/on), AECF_NO_WS,
- *      AECF_NO_GATE_FUSION, AECF_NO_WIDE_TN, AECF_NO_FUSED (A/B timing: route a shape through the fallback kernels);
+ *      AECF_NO_GATE_FUSION, AECF_NO_WIDE_TN (A/B timing: route a shape through the fallback kernels), AECF_FUSED_FWD
+ *      (=1: the one-kernel row-stationary forward instead of the weight-stationary kernel pair);
  *    * one non-blocking capture stream per device, created on first use;
  *    * a cache of at most 8 hipGraphExec_t, least-recently-used evicted (hipGraphExecDestroy), keyed on
  *      (forward/backward, device, B, M, E, H, dtype, mask mode, which optional pointers are set).  A shape is captured
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AECF_ABI_VERSION 3
+#define AECF_ABI_VERSION 4
 
 typedef enum aecf_status {
     AECF_OK = 0,
@@ -162,6 +163,10 @@ int aecf_pool_check(const aecf_pool_desc* d);
 /* scratch bytes needed by forward / backward for this description */
 size_t aecf_pool_fwd_workspace_bytes(const aecf_pool_desc* d);
 size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d);
+/* 1 when the backward of this description is faster with the forward's per-modality value projections
+ * (aecf_pool_fwd_args.saved_v), 0 when it derives the score gradient from x itself and saved_v should stay NULL
+ * (bf16, E in {256, 512}, M <= 4: the forward then writes B*M*E fewer elements) */
+int aecf_pool_wants_saved_v(const aecf_pool_desc* d);
 /* bytes of the optional parameter-preparation buffer shared by forward and backward (saved_prep) */
 size_t aecf_pool_prep_bytes(const aecf_pool_desc* d);
 
