@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libaecf_hip.so")
 AECF_ABI_VERSION = 4
 AECF_BF16 = 0
 AECF_F32 = 1
+AECF_PRECISE = 1
 AECF_FWD_STAGES = 4
 AECF_BWD_STAGES = 8
 
@@ -50,7 +51,7 @@ class PoolFwdArgs(Structure):
         ("stage_events", c_void_p),
         ("info_attn_w", c_void_p), ("info_masked_w", c_void_p), ("info_entropy", c_void_p),
         ("info_mask_rate", c_void_p), ("saved_prep", c_void_p),
-        ("info_target_entropy", c_void_p), ("target_entropy_value", c_float), ("reserved", c_int32),
+        ("info_target_entropy", c_void_p), ("target_entropy_value", c_float), ("flags", c_int32),
     ]
 
 
@@ -63,7 +64,7 @@ class PoolBwdArgs(Structure):
         ("dquery", c_void_p), ("dw_in", c_void_p), ("db_in", c_void_p), ("dw_out", c_void_p),
         ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
-        ("grad_dtype", c_int32), ("reserved", c_int32), ("saved_prep", c_void_p),
+        ("grad_dtype", c_int32), ("flags", c_int32), ("saved_prep", c_void_p),
     ]
 
 
@@ -98,6 +99,7 @@ _SYMBOLS = [
     ("aecf_pool_bwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_prep_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_wants_saved_v", c_int, [POINTER(PoolDesc)]),
+    ("aecf_pool_precise_workspace_bytes", c_size_t, [POINTER(PoolDesc), c_int]),
     ("aecf_pool_forward", c_int, [POINTER(PoolDesc), POINTER(PoolFwdArgs), c_void_p]),
     ("aecf_pool_backward", c_int, [POINTER(PoolDesc), POINTER(PoolBwdArgs), c_void_p]),
     ("aecf_curriculum_mask_forward", c_int,

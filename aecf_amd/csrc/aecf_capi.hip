@@ -108,6 +108,42 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     return w;
 }
 
+// ---- AECF_PRECISE: float32-store form of the bf16 path (include/aecf_hip.h) ------------------------------------------
+// forward workspace: [ordinary forward workspace of the bf16 description][w_out32 E*E][b_out32 E][o32 B*E (when the caller
+// keeps no saved_o)]
+struct PreciseFwdWs { size_t base, w_out32, b_out32, o32, total; };
+PreciseFwdWs precise_fwd_layout(const aecf_pool_desc* d) {
+    PreciseFwdWs w;
+    const size_t E = d->embed_dim, B = (size_t)d->batch;
+    size_t off = align_up(fwd_layout(d).total);
+    w.base = 0;
+    w.w_out32 = off; off = align_up(off + E * E * 4);
+    w.b_out32 = off; off = align_up(off + E * 4);
+    w.o32 = off;     off = align_up(off + B * E * 4);
+    w.total = off;
+    return w;
+}
+// backward workspace: [bf16 prep][x32][dy32][q32][w_in32][b_in32][w_out32][do32][float32 backward workspace]
+struct PreciseBwdWs { size_t prep16, x32, dy32, q32, w_in32, b_in32, w_out32, do32, ws32, total; };
+PreciseBwdWs precise_bwd_layout(const aecf_pool_desc* d) {
+    PreciseBwdWs w;
+    const size_t E = d->embed_dim, B = (size_t)d->batch, M = d->modalities;
+    aecf_pool_desc d32 = *d;
+    d32.dtype = AECF_F32;
+    size_t off = 0;
+    w.prep16 = off;  off = align_up(off + prep_layout(d).total);
+    w.x32 = off;     off = align_up(off + B * M * E * 4);
+    w.dy32 = off;    off = align_up(off + B * E * 4);
+    w.q32 = off;     off = align_up(off + E * 4);
+    w.w_in32 = off;  off = align_up(off + 3 * E * E * 4);
+    w.b_in32 = off;  off = align_up(off + 3 * E * 4);
+    w.w_out32 = off; off = align_up(off + E * E * 4);
+    w.do32 = off;    off = align_up(off + B * E * 4);
+    w.ws32 = off;    off = align_up(off + bwd_layout(&d32).total);
+    w.total = off;
+    return w;
+}
+
 inline void mark(void** ev, int i, hipStream_t s) {
     if (ev) (void)hipEventRecord((hipEvent_t)ev[i], s);
 }
@@ -178,6 +214,11 @@ size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d) {
     return bwd_layout(d).total;
 }
 
+size_t aecf_pool_precise_workspace_bytes(const aecf_pool_desc* d, int backward) {
+    if (aecf_pool_check(d) != AECF_OK || d->dtype != AECF_BF16) return 0;
+    return backward ? precise_bwd_layout(d).total : precise_fwd_layout(d).total;
+}
+
 int aecf_pool_wants_saved_v(const aecf_pool_desc* d) {
     if (aecf_pool_check(d) != AECF_OK) return 0;
     if (d->dtype == AECF_BF16 && !env_no_ws()) {
@@ -201,6 +242,9 @@ namespace {
 int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStream_t s) {
     int st = aecf_pool_check(d);
     if (st != AECF_OK) return st;
+    const bool precise = a && (a->flags & AECF_PRECISE);
+    if (precise && d->dtype != AECF_BF16) return AECF_ERR_UNSUPPORTED;
+    if (precise && a->workspace_bytes < precise_fwd_layout(d).total) return AECF_ERR_WORKSPACE;
     if (!a || !a->x || !a->query || !a->w_in || !a->w_out || !a->y || !a->attn_w || !a->saved_probs || !a->workspace)
         return AECF_ERR_NULL_POINTER;
     if (d->mask_mode == 1 && !a->uniforms) return AECF_ERR_NULL_POINTER;
@@ -216,7 +260,8 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     float* a_f32 = pb ? (float*)(pb + P.a_f32) : (float*)(ws + L.a_f32);
     void* a_hi = pb ? (void*)(pb + P.a_hi) : (void*)(ws + L.a_hi);
     void* a_lo = pb ? (void*)(pb + P.a_lo) : (void*)(ws + L.a_lo);
-    void* o = a->saved_o ? a->saved_o : (void*)(ws + L.obuf);
+    const PreciseFwdWs PW = precise ? precise_fwd_layout(d) : PreciseFwdWs{};
+    void* o = a->saved_o ? a->saved_o : (void*)(ws + (precise ? PW.o32 : L.obuf));     // (precise: float32 [B,E])
     const float scale = sqrtf(1.0f / (float)hd);     // torch functional.py:6577 q * sqrt(1/head_dim)
 
     void** ev = a->stage_events;
@@ -251,9 +296,9 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     v.a = a->x; v.w = (const char*)a->w_in + (size_t)2 * E * E * es;
     v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
     v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
-    v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = 0; v.v_out = a->saved_v;
+    v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = precise ? 1 : 0; v.v_out = precise ? nullptr : a->saved_v;
     if (frag) v.w_frag = ws + L.wv_frag;
-    if (env_fused_fwd() && row_fwd_supported(d->dtype, E, M, H)) {
+    if (env_fused_fwd() && !precise && row_fwd_supported(d->dtype, E, M, H)) {
         // ONE kernel from x to y: scores, softmax, statistics, value projection, pooling, out-projection (aecf_row_fwd.hip)
         GemmNtArgs yo;
         yo.a = o; yo.w = a->w_out; yo.bias = a->b_out; yo.c = a->y; yo.probs = nullptr; yo.R = d->batch; yo.N = E; yo.K = E;
@@ -281,15 +326,72 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     GemmNtArgs y;
     y.a = o; y.w = a->w_out; y.bias = a->b_out; y.c = a->y; y.probs = nullptr; y.R = d->batch; y.N = E; y.K = E;
     y.lda = E; y.M = 1; y.H = H; y.hd = hd; y.pooled = 0; y.out_f32 = 0; y.v_out = nullptr;
+    if (precise) {
+        // the out-projection consumes an intermediate (o): float32 operands, exact float32 MFMA, float32 y
+        launch_cast_bf16_f32(a->w_out, (float*)(ws + PW.w_out32), (int64_t)E * E, s);
+        launch_cast_bf16_f32(a->b_out, (float*)(ws + PW.b_out32), E, s);
+        y.w = ws + PW.w_out32;
+        y.bias = a->b_out ? (const void*)(ws + PW.b_out32) : nullptr;
+        launch_gemm_nt(AECF_F32, y, s);
+        mark(ev, 4, s);
+        return launch_status();
+    }
     if (frag) y.w_frag = ws + L.wo_frag;
     launch_gemm_nt(d->dtype, y, s);
     mark(ev, 4, s);
     return launch_status();
 }
 
-int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipStream_t s) {
+int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipStream_t s, const void* do_ready = nullptr);
+
+// AECF_PRECISE backward: do = dy W_o on the bf16 kernel (exact bf16 operands) stored in float32; everything that consumes
+// an intermediate (do, o) runs on the float32 kernels from float32 copies of the bf16 inputs
+int pool_backward_precise(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipStream_t s) {
+    if (d->dtype != AECF_BF16 || a->grad_dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (!a->x || !a->query || !a->w_in || !a->w_out || !a->dy || !a->workspace) return AECF_ERR_NULL_POINTER;
+    const PreciseBwdWs L = precise_bwd_layout(d);
+    if (a->workspace_bytes < L.total) return AECF_ERR_WORKSPACE;
+    char* ws = (char*)a->workspace;
+    const int E = d->embed_dim, H = d->num_heads, M = d->modalities, hd = E / H;
+    const int64_t B = d->batch;
+    launch_cast_bf16_f32(a->x, (float*)(ws + L.x32), B * M * E, s);
+    launch_cast_bf16_f32(a->dy, (float*)(ws + L.dy32), B * E, s);
+    launch_cast_bf16_f32(a->query, (float*)(ws + L.q32), E, s);
+    launch_cast_bf16_f32(a->w_in, (float*)(ws + L.w_in32), (int64_t)3 * E * E, s);
+    launch_cast_bf16_f32(a->b_in, (float*)(ws + L.b_in32), 3 * E, s);
+    launch_cast_bf16_f32(a->w_out, (float*)(ws + L.w_out32), (int64_t)E * E, s);
+    // bf16 preparation (W_o^T and its fragment copy), then do = dy W_o with float32 stores
+    const PrepWs P = prep_layout(d);
+    char* pb = ws + L.prep16;
+    const float scale = sqrtf(1.0f / (float)hd);
+    const char* w_v = (const char*)a->w_in + (size_t)2 * E * E * 2;
+    const bool frag = (E == 256 || E == 512 || E == 768 || E == 1024) && !env_no_ws();
+    FragJobs fj;
+    if (frag) {
+        fj.n = 2;
+        fj.src[0] = w_v;      fj.dst[0] = pb + P.wvt_frag; fj.transposed[0] = 1;
+        fj.src[1] = a->w_out; fj.dst[1] = pb + P.wot_frag; fj.transposed[1] = 1;
+    }
+    launch_prep_all(AECF_BF16, a->w_in, a->b_in, a->query, scale, (float*)(pb + P.qs), (float*)(pb + P.a_f32), pb + P.a_hi,
+                    pb + P.a_lo, w_v, pb + P.wvt, a->w_out, pb + P.wot, E, H, fj, s);
+    GemmNtArgs g;
+    g.a = a->dy; g.w = pb + P.wot; g.bias = nullptr; g.c = ws + L.do32; g.probs = nullptr; g.R = B; g.N = E; g.K = E; g.lda = E;
+    g.M = 1; g.H = H; g.hd = hd; g.pooled = 0; g.out_f32 = 1; g.v_out = nullptr;
+    if (frag) g.w_frag = pb + P.wot_frag;
+    launch_gemm_nt(AECF_BF16, g, s);
+    aecf_pool_desc d32 = *d;
+    d32.dtype = AECF_F32;
+    aecf_pool_bwd_args a32 = *a;
+    a32.x = ws + L.x32; a32.query = ws + L.q32; a32.w_in = ws + L.w_in32; a32.b_in = a->b_in ? (const void*)(ws + L.b_in32) : nullptr;
+    a32.w_out = ws + L.w_out32; a32.dy = ws + L.dy32; a32.saved_v = nullptr; a32.saved_prep = nullptr;
+    a32.workspace = ws + L.ws32; a32.workspace_bytes = a->workspace_bytes - L.ws32; a32.flags = 0; a32.stage_events = nullptr;
+    return pool_backward_on(&d32, &a32, s, ws + L.do32);
+}
+
+int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipStream_t s, const void* do_ready) {
     int st = aecf_pool_check(d);
     if (st != AECF_OK) return st;
+    if (a && (a->flags & AECF_PRECISE)) return pool_backward_precise(d, a, s);
     if (!a || !a->x || !a->query || !a->w_in || !a->w_out || !a->dy || !a->saved_probs || !a->saved_o || !a->dx ||
         !a->dquery || !a->dw_in || !a->db_in || !a->dw_out || !a->db_out || !a->workspace)
         return AECF_ERR_NULL_POINTER;
@@ -306,7 +408,7 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     float* a_f32 = (float*)(pb + P.a_f32);
     void* wvt = pb + P.wvt;
     void* wot = pb + P.wot;
-    void* dobuf = ws + L.dobuf;
+    void* dobuf = do_ready ? const_cast<void*>(do_ready) : (void*)(ws + L.dobuf);
     float* dsbuf = (float*)(ws + L.dsbuf);
     float* u = (float*)(ws + L.u);
     const float scale = sqrtf(1.0f / (float)hd);
@@ -332,7 +434,7 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     g.a = a->dy; g.w = wot; g.bias = nullptr; g.c = dobuf; g.probs = nullptr; g.R = B; g.N = E; g.K = E; g.lda = E;
     g.M = 1; g.H = H; g.hd = hd; g.pooled = 0; g.out_f32 = 0; g.v_out = nullptr;
     if (frag) g.w_frag = pb + P.wot_frag;
-    launch_gemm_nt(d->dtype, g, s);
+    if (!do_ready) launch_gemm_nt(d->dtype, g, s);
     mark(ev, 2, s);
 
     // dW_o = dy^T o, db_o = colsum(dy)
@@ -572,7 +674,7 @@ extern "C" {
 
 int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream) {
     hipStream_t user = (hipStream_t)stream;
-    if (d && a && !a->stage_events && graphs_enabled(d)) {         // (the per-stage events need the plain launches)
+    if (d && a && !a->stage_events && !(a->flags & AECF_PRECISE) && graphs_enabled(d)) {   // (stage events / precise: plain launches)
         const GraphKey key{0, 0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
                            (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->key_padding_mask ? 4 : 0)};
         int status = AECF_OK;
@@ -583,7 +685,7 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
 
 int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream) {
     hipStream_t user = (hipStream_t)stream;
-    if (d && a && !a->stage_events && graphs_enabled(d)) {
+    if (d && a && !a->stage_events && !(a->flags & AECF_PRECISE) && graphs_enabled(d)) {
         const GraphKey key{1, 0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
                            (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->d_entropy ? 4 : 0) | (a->grad_dtype << 4)};
         int status = AECF_OK;

@@ -92,6 +92,12 @@ __device__ __forceinline__ void store_packed(unsigned short* dst, const unsigned
     if (CT == 2) *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
     else *reinterpret_cast<u32x2*>(dst) = u32x2{pk[0], pk[1]};
 }
+// the same columns as float32 (precise mode: intermediates and outputs are not rounded to bf16)
+template <int CT>
+__device__ __forceinline__ void store_cols_f32(float* dst, const float* v) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    if (CT == 2) *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
 template <int CT>
 __device__ __forceinline__ void store_cols(unsigned short* dst, const float* v) {
     if (CT == 2) {
@@ -368,7 +374,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[t][c][r] + bias[4 * c + r];
                 if (!VF) {
-                    if (row < o_end) store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + NV * lg, v);
+                    if (row < o_end) {
+                        if (p.out_f32) store_cols_f32<CT>(reinterpret_cast<float*>(p.c) + row * N + ncol0 + NV * lg, v);
+                        else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + NV * lg, v);
+                    }
                 } else {
                     if (p.v_out && row < o_end)
                         store_cols<CT>(reinterpret_cast<unsigned short*>(p.v_out) + row * N + ncol0 + NV * lg, v);
@@ -392,7 +401,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
                     for (int m = 0; m < M_; ++m)
                         store_packed<CT>(reinterpret_cast<unsigned short*>(p.v_out) + (b * M_ + m) * N + ncol0 + NV * lg, vpk[m]);
                 }
-                store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + NV * lg, ov);
+                if (p.out_f32) store_cols_f32<CT>(reinterpret_cast<float*>(p.c) + b * N + ncol0 + NV * lg, ov);
+                else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + NV * lg, ov);
             }
         }
     }
@@ -698,7 +708,6 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     // ds threads: one wave per local head, lane = 16 m + sample (lane groups m >= M_ idle): the partial dots of a lane's
     // (sample, m) are contiguous over the lanes (conflict-free LDS reads), the sum over m is a lane-group reduction
     const int ds_s = lane & 15, ds_hh = w, ds_m = lg;
-    const bool ds_thread = w < HBL && ds_m < M_;
     const float invH = 1.0f / (float)H;
     // softmax weight and upstream weight gradient of a step, fetched one step ahead by inline-asm loads (see
     // ws_dma_rows_asm: an ordinary load here would serialise the LDS-DMA with the compute); retired by the step's
@@ -974,7 +983,8 @@ static bool ws_vproj_flat(const GemmNtArgs& a) {
 }
 
 bool gemm_ws_supported(const GemmNtArgs& a) {
-    if (a.out_f32 || !ws_k_ok(a.K)) return false;
+    if (!ws_k_ok(a.K)) return false;
+    if (a.out_f32 && (a.pooled & 1) && ws_vproj_flat(a)) return false;    // (the flat-row form stores bf16 only)
     const int ct = a.K <= 512 ? 2 : 1;
     if (a.N % (128 * ct) != 0) return false;
     const bool vproj = (a.pooled & 1) != 0;

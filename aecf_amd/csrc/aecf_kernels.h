@@ -199,6 +199,7 @@ void launch_nce_rows(int dtype, int64_t rows, int64_t cols, int64_t row_offset, 
 void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat, const uint8_t* drop, void* out,
                               uint8_t* present, hipStream_t s);
 void launch_transpose_rect(int dtype, const void* src, void* dst, int64_t R, int64_t C, hipStream_t s);
+void launch_cast_bf16_f32(const void* src, float* dst, int64_t n, hipStream_t s);     // 16-byte aligned src / dst
 
 // ---------------- presence routing (aecf_route.hip) ----------------
 void launch_route_build(int64_t rows, const uint8_t* pa, const uint8_t* pb, int32_t* route, int32_t* slot, int32_t* index,

@@ -285,6 +285,24 @@ __global__ __launch_bounds__(256) void modality_frontend_kernel(int64_t rows, in
     if (lane == 0) present[r] = sqrtf(ss) > 1e-6f ? 1 : 0;
 }
 
+// bf16 -> float32, n elements (precise mode: the intermediates' consumers run on the float32 kernels)
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        float v[8];
+        Tr<BF16>::unpack(*reinterpret_cast<const u32x4*>(src + i), v);
+        *reinterpret_cast<f32x4*>(dst + i) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(dst + i + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = Tr<BF16>::to_f32(src[j]);
+    }
+}
+
+void launch_cast_bf16_f32(const void* src, float* dst, int64_t n, hipStream_t s) {
+    if (n <= 0 || !src) return;
+    cast_bf16_f32_kernel<<<dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s>>>((const unsigned short*)src, dst, n);
+}
+
 void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat, const uint8_t* drop, void* out,
                               uint8_t* present, hipStream_t s) {
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);

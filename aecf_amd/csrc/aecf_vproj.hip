@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
     }
     // ---- stores.  bf16: ONE LDS pass -- image [64 rows][1 + M slots][128 cols] (slot 0 = o, slot 1+m = V_m, the
     //      per-modality products W x_m + bias kept for the backward score gradient), then full-row 16-byte stores.
-    if (X::BYTES == 2) {
+    if (X::BYTES == 2 && !p.out_f32) {
         const int nslot = p.v_out ? M_ + 1 : 1;
         const int pitch = nslot * 256;
         __syncthreads();
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         const int64_t row = r0 + 32 * wr + 16 * rt + 4 * lg + r;
                         if (row < p.R) {
-                            c[row * p.N + n] = X::from_f32(o[rt][ct][r]);
+                            if (X::BYTES == 2) reinterpret_cast<float*>(p.c)[row * p.N + n] = o[rt][ct][r];    // out_f32
+                            else c[row * p.N + n] = X::from_f32(o[rt][ct][r]);
                             if (vo) {
 #pragma unroll
                                 for (int m = 0; m < M_; ++m) vo[(row * M_ + m) * p.N + n] = X::from_f32(acc[m][rt][ct][r] + bv);

@@ -117,8 +117,16 @@ typedef struct aecf_pool_fwd_args {
      * [B] dtype filled with target_entropy_value by the kernel that writes the other info tensors; NULL = not wanted */
     void* info_target_entropy;
     float target_entropy_value;  /* the caller's log(M) * entropy_target, rounded to float32 */
-    int32_t reserved;
+    /* AECF_PRECISE (desc.dtype == AECF_BF16 only): the float32-STORE form of the bf16 path ("bf16
+     * tolerance"): x / query / weights are bf16 as usual and every product of exact bf16 operands runs on the bf16 MFMA
+     * kernels, but no intermediate is rounded to bf16 -- the pooled heads o are kept in float32 and the products that
+     * consume an intermediate accumulate from it in float32.  y, saved_o (and in the backward dx and all parameter
+     * gradients) are then float32 buffers; workspace = aecf_pool_precise_workspace_bytes.  A verification mode (it moves
+     * twice the bytes): what "outputs match within 1e-3 relative, bf16" is asserted on. */
+    int32_t flags;
 } aecf_pool_fwd_args;
+
+#define AECF_PRECISE 1
 
 /* Backward (autograd transpose of the above). */
 typedef struct aecf_pool_bwd_args {
@@ -146,7 +154,7 @@ typedef struct aecf_pool_bwd_args {
     /* element type of the five parameter gradients: AECF_F32, or AECF_BF16 when desc.dtype is AECF_BF16 (the
      * float32 batch sums are rounded once, in the reduction kernel -- what autograd's cast to a bf16 parameter does) */
     int32_t grad_dtype;
-    int32_t reserved;
+    int32_t flags;               /* AECF_PRECISE: dy bf16; saved_o, dx and the gradients float32 (see aecf_pool_fwd_args.flags) */
     const void* saved_prep;      /* buffer filled by aecf_pool_forward (see aecf_pool_fwd_args.saved_prep) or NULL */
 } aecf_pool_bwd_args;
 
@@ -167,6 +175,8 @@ size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d);
  * (aecf_pool_fwd_args.saved_v), 0 when it derives the score gradient from x itself and saved_v should stay NULL
  * (bf16, E in {256, 512}, M <= 4: the forward then writes B*M*E fewer elements) */
 int aecf_pool_wants_saved_v(const aecf_pool_desc* d);
+/* workspace bytes of a call with AECF_PRECISE set (backward == 0: forward) */
+size_t aecf_pool_precise_workspace_bytes(const aecf_pool_desc* d, int backward);
 /* bytes of the optional parameter-preparation buffer shared by forward and backward (saved_prep) */
 size_t aecf_pool_prep_bytes(const aecf_pool_desc* d);
 

@@ -396,6 +396,54 @@ def g10_model_step():
     print("g10 model step: loss", float(loss), "params", sum(p.numel() for p in model.parameters()))
 
 
+def g6_bf16_envelope():
+    """Fixture G6: the reference's OWN bf16 path -- the reference module with bf16 parameters on bf16 inputs,
+    CPU -- on the inputs of the g2 bf16 fixtures and on seeded inputs at the headline shape, measured against fp32 math
+    on the same (bf16-representable) values.  Stored: the per-tensor max-norm relative error of the reference's bf16
+    outputs.  The HIP bf16 path must be no worse than this envelope (tests/test_pool_gpu.py)."""
+    import glob
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests.helpers import hot_shape_inputs, rel_err
+    out = {}
+
+    def run(d, dtype, kpm):
+        E, H, B = int(d["E"]), int(d["H"]), int(d["B"])
+        pool = ref.MultimodalAttentionPool(E, num_heads=H)
+        with torch.no_grad():
+            pool.attention.in_proj_weight.copy_(torch.as_tensor(d["w_in"]))
+            pool.attention.in_proj_bias.copy_(torch.as_tensor(d["b_in"]))
+            pool.attention.out_proj.weight.copy_(torch.as_tensor(d["w_out"]))
+            pool.attention.out_proj.bias.copy_(torch.as_tensor(d["b_out"]))
+        pool = pool.to(dtype).train()
+        x = torch.as_tensor(d["x"]).to(dtype).requires_grad_(True)
+        q0 = torch.as_tensor(d["query"]).to(dtype).requires_grad_(True)
+        y, info = pool(q0.expand(B, -1, -1), x, key_padding_mask=kpm, return_info=True)
+        wbar = info["attention_weights"]
+        ((y.float() * torch.as_tensor(d["dy"])).sum() + (wbar.float() * torch.as_tensor(d["dwbar"])).sum()).backward()
+        a = pool.attention
+        res = dict(y=y, wbar=wbar, dx=x.grad, dquery=q0.grad, dw_in=a.in_proj_weight.grad, db_in=a.in_proj_bias.grad,
+                   dw_out=a.out_proj.weight.grad, db_out=a.out_proj.bias.grad)
+        return {k: v.detach().float() for k, v in res.items()}
+
+    cases = []
+    for path in sorted(glob.glob(os.path.join(HERE, "g2_mha_bf16_*.npz"))):
+        z = np.load(path)
+        cases.append((os.path.basename(path)[:-4], {k: z[k] for k in z.files}))
+    for seed in (61, 62):
+        cases.append((f"hot_seed{seed}", {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in hot_shape_inputs(seed).items()}))
+    for name, d in cases:
+        kpm = torch.as_tensor(d["key_padding_mask"]) if "key_padding_mask" in d else None
+        truth = run(d, torch.float32, kpm)
+        got = run(d, torch.bfloat16, kpm)
+        out[name] = {k: rel_err(got[k], truth[k]) for k in truth}
+        if name.startswith("g2_"):       # the stored fp32 outputs of the g2 fixture are this same truth
+            assert rel_err(truth["y"], d["y"]) < 1e-6 and rel_err(truth["dx"], d["dx"]) < 1e-6
+        print("g6", name, {k: f"{v:.2e}" for k, v in out[name].items()})
+    with open(os.path.join(HERE, "g6_bf16_envelope.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def g11_general():
     """nn.MultiheadAttention options outside the shared-query path, from the reference module itself:
     attn_mask (bool 2-D, float 3-D), key_padding_mask, key != value, tgt_len > 1, per-sample queries, seq-first."""
@@ -459,6 +507,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g10":
         g10_model_step()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g6":
+        g6_bf16_envelope()
+        sys.exit(0)
     # fp32 inputs, full mantissa
     g2_case("e64h1m2", 64, 1, 2, 48, seed=1)
     g2_case("e64h4m3", 64, 4, 3, 64, seed=2)
@@ -482,3 +533,4 @@ if __name__ == "__main__":
     g8_options()
     g9_validation()
     g10_model_step()
+    g6_bf16_envelope()

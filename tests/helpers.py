@@ -41,3 +41,21 @@ def rel_err(got, want):
 
 def parse_float(s):
     return float(s)
+
+
+def hot_shape_inputs(seed, B=256, M=3, E=512, H=8):
+    """Seeded bf16-representable inputs and parameters at the headline shape (d=512, 8 heads, M=3), built the same way by
+    tests/golden/make_golden.py (fixture G6) and by the GPU tests: CPU generator, so identical on every machine."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *shape: torch.randn(*shape, generator=g)
+    bf = lambda t_: t_.to(torch.bfloat16).to(torch.float32)
+    d = dict(B=B, M=M, E=E, H=H)
+    d["x"] = bf(r(B, M, E) * torch.tensor([1.0, 1.5, 2.0][:M]).view(1, M, 1))
+    d["query"] = bf(r(1, 1, E) * (2.0 / E) ** 0.5)
+    d["w_in"] = bf(r(3 * E, E) * (1.0 / E) ** 0.5)
+    d["b_in"] = bf(r(3 * E) * 0.05)
+    d["w_out"] = bf(r(E, E) * (1.0 / E) ** 0.5)
+    d["b_out"] = bf(r(E) * 0.05)
+    d["dy"] = bf(r(B, 1, E))
+    d["dwbar"] = bf(r(B, 1, M))
+    return d
