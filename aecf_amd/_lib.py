@@ -121,6 +121,9 @@ _SYMBOLS = [
     ("aecf_mha_forward", c_int, [POINTER(MhaDesc), POINTER(MhaFwdArgs), c_void_p]),
     ("aecf_mha_backward", c_int, [POINTER(MhaDesc), POINTER(MhaBwdArgs), c_void_p]),
     ("aecf_modality_frontend", c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("aecf_loss_fwd_bwd", c_int,
+     [c_int64, c_int64, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+      c_int32, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("aecf_route_build", c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_rows_gather", c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     ("aecf_rows_select", c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -760,6 +760,23 @@ int aecf_modality_frontend(int64_t rows, int32_t dim, int32_t dtype, const void*
     return launch_status();
 }
 
+int aecf_loss_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef, const void* q,
+                      const void* k, float* loss_rows, float* dq, float* dk, int64_t n_entropy, int32_t last_seq_len,
+                      float entropy_target, const float* entropy, float entropy_upstream, float* entropy_loss,
+                      float* d_entropy, void* workspace, size_t workspace_bytes, void* stream) {
+    if (rows <= 0 || cols <= 0 || d <= 0 || temperature <= 0.f || n_entropy < 0) return AECF_ERR_BAD_DIMS;
+    if (row_offset < 0 || row_offset + rows > cols) return AECF_ERR_BAD_DIMS;
+    if (!nce_flash_supported(AECF_BF16, d)) return AECF_ERR_UNSUPPORTED;
+    if (!q || !k || !loss_rows || !dq || !dk || !workspace) return AECF_ERR_NULL_POINTER;
+    if (n_entropy > 0 && (!entropy || !entropy_loss)) return AECF_ERR_NULL_POINTER;
+    if (workspace_bytes < nce_flash_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
+    const double max_ent = last_seq_len > 1 ? log((double)last_seq_len) : 0.0;       // ref :301-308
+    launch_nce_flash(rows, cols, row_offset, d, 1.0f / temperature, coef, q, k, loss_rows, dq, dk, workspace,
+                     n_entropy > 0 ? entropy : nullptr, n_entropy, (float)(max_ent * (double)entropy_target), entropy_upstream,
+                     d_entropy, entropy_loss, (hipStream_t)stream);
+    return launch_status();
+}
+
 int aecf_route_build(int64_t rows, const uint8_t* present_a, const uint8_t* present_b, int32_t* route, int32_t* slot,
                      int32_t* index, int32_t* counts, void* stream) {
     if (rows <= 0 || rows > 0x7fffffff) return AECF_ERR_BAD_DIMS;
@@ -810,6 +827,7 @@ int aecf_l2norm_backward(int64_t n, int32_t d, int32_t dtype, const void* zn, co
 
 size_t aecf_nce_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype) {
     if (rows <= 0 || cols <= 0 || d <= 0) return 0;
+    if (nce_flash_supported(dtype, d)) return nce_flash_workspace_bytes(rows, cols, d);
     const size_t es = esize(dtype);
     return align_up((size_t)rows * cols * 4) + align_up((size_t)rows * cols * es) + align_up((size_t)d * cols * es);
 }
@@ -820,8 +838,14 @@ int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, 
     if (rows <= 0 || cols <= 0 || d <= 0 || temperature <= 0.f) return AECF_ERR_BAD_DIMS;
     if (row_offset < 0 || row_offset + rows > cols) return AECF_ERR_BAD_DIMS;
     if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
-    if (d % 64 != 0 || cols % 64 != 0) return AECF_ERR_UNSUPPORTED;
     if (!q || !k || !loss_rows || !dq || !dk || !workspace) return AECF_ERR_NULL_POINTER;
+    if (nce_flash_supported(dtype, d)) {         // streaming form: any rows / cols, workspace O(rows d)
+        if (workspace_bytes < nce_flash_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
+        launch_nce_flash(rows, cols, row_offset, d, 1.0f / temperature, coef, q, k, loss_rows, dq, dk, workspace, nullptr, 0,
+                         0.f, 0.f, nullptr, nullptr, (hipStream_t)stream);
+        return launch_status();
+    }
+    if (d % 64 != 0 || cols % 64 != 0) return AECF_ERR_UNSUPPORTED;
     if (workspace_bytes < aecf_nce_workspace_bytes(rows, cols, d, dtype)) return AECF_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const size_t es = esize(dtype);

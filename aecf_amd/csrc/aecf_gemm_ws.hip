@@ -51,35 +51,6 @@ __device__ __forceinline__ void ws_dma_rows(const char* __restrict__ src, unsign
     }
 }
 
-// the same copy issued through inline asm: invisible to hipcc's waitcnt insertion, which otherwise puts s_waitcnt vmcnt(0)
-// in front of the first LDS read that follows a global_load_lds it can see whenever ordinary loads are in flight as well
-// (the copy would then be serialised with the compute of the step it is meant to fly behind).  The caller retires it with
-// its own s_waitcnt vmcnt(0).
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-template <int KT, int NROWS, int KEYDIV>
-__device__ __forceinline__ void ws_dma_rows_asm(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid, char* lds) {
-    constexpr int CPR = 4 * KT;
-    constexpr int TOTAL = NROWS * CPR;
-    constexpr int NI = (TOTAL + 511) / 512;
-    static_assert(TOTAL % 64 == 0, "whole wave-instructions");
-    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        if (wbase + 512 * i < TOTAL) {                // wave-uniform
-            const int c = threadIdx.x + 512 * i;
-            const int row = c / CPR, p = c - row * CPR;
-            const int rowc = row < rows_valid ? row : rows_valid - 1;
-            const int key = (row / KEYDIV) & 15;
-            const unsigned int voff = (unsigned)rowc * ld_bytes + (unsigned)((p ^ key) << 4);
-            const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(lds + (wbase + 512 * i) * 16);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst)
-                         : "memory", "m0");
-        }
-    }
-}
-#pragma clang diagnostic pop
-
 // GATE (VPROJ only): the softmax weights are PRODUCED here instead of read -- scores x . A[h] against the folded key
 // matrix (bf16 hi/lo split), one more use of the tile that is already in LDS, so the separate gate kernel and its pass
 // over x disappear.  Each wave takes KG = KT/8 K-steps of the score product for all 16 heads x 16 samples x M
@@ -106,17 +77,6 @@ __device__ __forceinline__ void store_cols(unsigned short* dst, const float* v) 
     } else {
         *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
-}
-
-// MFMA A/B operand of 8 consecutive ROWS (the K index) at one column per lane, from a row-major LDS tile, by two
-// transposed reads (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block, lane i receives column i)
-typedef short v4i16_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
-__device__ __forceinline__ u32x4 tr_frag16(const char* tile, int addr_lo, int addr_hi) {
-    const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(tile + addr_lo));
-    const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(tile + addr_hi));
-    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
-    return u32x4{l[0], l[1], h[0], h[1]};
 }
 
 // CT = column tiles (of 16) per wave: 2 for K <= 512 (32 columns x K weights = up to 128 VGPRs, a block owns 256 columns),

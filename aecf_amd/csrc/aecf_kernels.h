@@ -201,6 +201,13 @@ void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat
 void launch_transpose_rect(int dtype, const void* src, void* dst, int64_t R, int64_t C, hipStream_t s);
 void launch_cast_bf16_f32(const void* src, float* dst, int64_t n, hipStream_t s);     // 16-byte aligned src / dst
 
+// flash-style InfoNCE direction (aecf_nce_flash.hip): no [rows, cols] logits; optional entropy regulariser in the same call
+bool nce_flash_supported(int dtype, int d);
+size_t nce_flash_workspace_bytes(int64_t rows, int64_t cols, int d);
+void launch_nce_flash(int64_t rows, int64_t cols, int64_t row_offset, int d, float inv_temp, float coef, const void* q,
+                      const void* k, float* loss_rows, float* dq, float* dk, void* workspace, const float* ent, int64_t n_ent,
+                      float ent_target, float ent_upstream, float* d_ent, float* ent_loss, hipStream_t s);
+
 // ---------------- presence routing (aecf_route.hip) ----------------
 void launch_route_build(int64_t rows, const uint8_t* pa, const uint8_t* pb, int32_t* route, int32_t* slot, int32_t* index,
                         int32_t* counts, hipStream_t s);

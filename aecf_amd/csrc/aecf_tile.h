@@ -90,6 +90,48 @@ __device__ __forceinline__ void dma_tile(const char* __restrict__ src, int64_t l
     }
 }
 
+// ---- row tiles of the weight-stationary / streaming kernels: NROWS rows of 64 KT bytes, 16-byte chunk p of row r stored
+// at chunk p ^ key(r), key(r) = (r / KEYDIV) & 15 (conflict-free ds_read_b128 fragment reads of 16 consecutive rows) ----
+// LDS-DMA of such a tile issued through inline asm: invisible to hipcc's waitcnt insertion, which otherwise puts s_waitcnt vmcnt(0)
+// in front of the first LDS read that follows a global_load_lds it can see whenever ordinary loads are in flight as well
+// (the copy would then be serialised with the compute of the step it is meant to fly behind).  The caller retires it with
+// its own s_waitcnt vmcnt(0).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <int KT, int NROWS, int KEYDIV, int NT = 512>
+__device__ __forceinline__ void ws_dma_rows_asm(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid, char* lds) {
+    constexpr int CPR = 4 * KT;
+    constexpr int TOTAL = NROWS * CPR;
+    constexpr int NI = (TOTAL + NT - 1) / NT;
+    static_assert(TOTAL % 64 == 0, "whole wave-instructions");
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (wbase + NT * i < TOTAL) {                 // wave-uniform
+            const int c = threadIdx.x + NT * i;
+            const int row = c / CPR, p = c - row * CPR;
+            const int rowc = row < rows_valid ? row : rows_valid - 1;
+            const int key = (row / KEYDIV) & 15;
+            const unsigned int voff = (unsigned)rowc * ld_bytes + (unsigned)((p ^ key) << 4);
+            const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(lds + (wbase + NT * i) * 16);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst)
+                         : "memory", "m0");
+        }
+    }
+}
+#pragma clang diagnostic pop
+
+// MFMA A/B operand of 8 consecutive ROWS (the K index) at one column per lane, from a row-major LDS tile, by two
+// transposed reads (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block, lane i receives column i)
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
+__device__ __forceinline__ u32x4 tr_frag16(const char* tile, int addr_lo, int addr_hi) {
+    const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(tile + addr_lo));
+    const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(tile + addr_hi));
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l[0], l[1], h[0], h[1]};
+}
+
 template <typename T>
 __device__ __forceinline__ typename Tr<T>::frag lds_frag(const char* lds, int row, int chunk) {
     return *reinterpret_cast<const typename Tr<T>::frag*>(lds + lds_off(row, chunk));

@@ -80,6 +80,57 @@ class _NceDirection(torch.autograd.Function):
         return (dq * g).to(ctx.dtypes[0]), (dk * g).to(ctx.dtypes[1]), None, None, None
 
 
+class _LossDirection(torch.autograd.Function):
+    """aecf_loss_fwd_bwd: ONE call for one InfoNCE direction (streaming form: no [rows, cols] logits) AND the entropy
+    regulariser of the reference (CurriculumMasking.entropy_loss, ref aecf/AECFLayer.py:285-314) with their gradients
+    -- BASELINE.json north_star's "second fused kernel".  Returns (contrastive share, entropy loss)."""
+
+    @staticmethod
+    def forward(ctx, q, k_all, entropy, row_offset, temperature, coef, last_seq_len, entropy_target):
+        lib = _lib.load()
+        rows, d = q.shape
+        cols = k_all.shape[0]
+        dev = q.device
+        qc, kc = q.detach().to(torch.bfloat16).contiguous(), k_all.detach().to(torch.bfloat16).contiguous()
+        ent = entropy.detach().to(torch.float32).contiguous().reshape(-1)
+        f32 = dict(dtype=torch.float32, device=dev)
+        loss_rows, dq, dk = torch.empty(rows, **f32), torch.empty(rows, d, **f32), torch.empty(cols, d, **f32)
+        ent_loss, dent = torch.empty(1, **f32), torch.empty(ent.numel(), **f32)
+        ws_bytes = lib.aecf_nce_workspace_bytes(rows, cols, d, _lib.AECF_BF16)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.aecf_loss_fwd_bwd(rows, cols, row_offset, d, temperature, coef, _ptr(qc), _ptr(kc), _ptr(loss_rows),
+                                         _ptr(dq), _ptr(dk), ent.numel(), last_seq_len, entropy_target, _ptr(ent), 1.0,
+                                         _ptr(ent_loss), _ptr(dent), _ptr(ws), ws_bytes, _stream()), "aecf_loss_fwd_bwd")
+        ctx.save_for_backward(dq, dk, dent)
+        ctx.meta = (q.dtype, k_all.dtype, entropy.dtype, entropy.shape)
+        return loss_rows.sum() * coef, ent_loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_nce, d_ent):
+        dq, dk, dent = ctx.saved_tensors
+        qd, kd, ed, eshape = ctx.meta
+        g = d_nce.to(torch.float32)
+        return ((dq * g).to(qd), (dk * g).to(kd), (dent * d_ent.to(torch.float32)).reshape(eshape).to(ed),
+                None, None, None, None, None)
+
+
+def contrastive_entropy_loss(za: torch.Tensor, zb: torch.Tensor, masking: CurriculumMasking, entropy: torch.Tensor,
+                             temperature: float = 0.07, entropy_weight: float = 0.01,
+                             contrastive_weight: float = 1.0) -> torch.Tensor:
+    """``contrastive_weight * info_nce(za, zb) + entropy_weight * masking.entropy_loss(entropy)`` (single rank, bf16
+    embeddings) with the entropy regulariser riding in the launch of the first InfoNCE direction (aecf_loss_fwd_bwd)."""
+    _require_device(za, "za")
+    if za.shape != zb.shape or za.dim() != 2:
+        raise ValueError(f"expected two [b, d] tensors of equal shape, got {tuple(za.shape)} and {tuple(zb.shape)}")
+    na, nb = l2_normalize(za), l2_normalize(zb)
+    coef = 0.5 / float(za.shape[0])
+    seq_len = masking._last_seq_len if hasattr(masking, "_last_seq_len") else 2
+    l_ab, l_ent = _LossDirection.apply(na, nb, entropy, 0, float(temperature), coef, int(seq_len),
+                                       float(masking.entropy_target))
+    l_ba = _NceDirection.apply(nb, na, 0, float(temperature), coef)
+    return contrastive_weight * (l_ab + l_ba) + entropy_weight * l_ent.to(za.dtype)
+
+
 def l2_normalize(z: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     _require_device(z, "z")
     return _L2Norm.apply(z, float(eps))
@@ -87,7 +138,8 @@ def l2_normalize(z: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
 
 def info_nce(za: torch.Tensor, zb: torch.Tensor, temperature: float = 0.07, group=None) -> torch.Tensor:
     """Symmetric InfoNCE between the local rows of two views with negatives from every rank of ``group``.
-    ``za``, ``zb``: [b_local, d] on a ROCm device, d % 64 == 0, total rows over ranks % 64 == 0."""
+    ``za``, ``zb``: [b_local, d] on a ROCm device.  bfloat16 with d in {128, 256, 384, 512, 768, 1024} runs the streaming
+    form (no [rows, cols] logits, any row counts); otherwise d % 64 == 0 and total rows over ranks % 64 == 0."""
     _require_device(za, "za")
     _require_device(zb, "zb")
     if za.shape != zb.shape or za.dim() != 2:

@@ -326,11 +326,25 @@ int aecf_l2norm_backward(int64_t n, int32_t d, int32_t dtype, const void* zn, co
  *   loss_rows[i] = logsumexp_j(q_i.k_j / T) - q_i.k_pos / T                       float32 [rows]
  *   dq = coef/T * (softmax - onehot) k          float32 [rows,d]
  *   dk = coef/T * (softmax - onehot)^T q        float32 [cols,d]   (sum over ranks is the caller's reduce-scatter)
- * d % 64 == 0, cols % 64 == 0. */
+ * bf16 with d in {128, 256, 384, 512, 768, 1024}: streaming ("flash") form -- the [rows, cols] logits are never
+ * materialised: key tiles stream through LDS under an online max / sum per row (the gradient on q is the attention
+ * output with V = K), a second streaming pass forms dk from the saved log-sum-exp; any rows / cols, workspace
+ * O(rows d).  Otherwise (float32, other d): materialising form, d % 64 == 0 and cols % 64 == 0. */
 size_t aecf_nce_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype);
 int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, int32_t dtype,
                      float temperature, float coef, const void* q, const void* k, float* loss_rows,
                      float* dq, float* dk, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The loss side of the objective as ONE call (BASELINE.json north_star "contrastive + entropy_loss terms and their backward
+ * are a second fused kernel"; README.md:205-208 of the reference for the entropy term): one InfoNCE direction exactly as
+ * aecf_nce_fwd_bwd (bf16, streaming form) and, riding in its row-combine launch, CurriculumMasking.entropy_loss forward +
+ * backward (ref aecf/AECFLayer.py:285-314) on entropy [n_entropy] float32:
+ *   entropy_loss[0] = mean((nan_to_num(H) - log(last_seq_len) * entropy_target)^2), d_entropy = d loss / dH * entropy_upstream.
+ * n_entropy == 0: contrastive term only.  Workspace: aecf_nce_workspace_bytes(rows, cols, d, AECF_BF16). */
+int aecf_loss_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef,
+                      const void* q, const void* k, float* loss_rows, float* dq, float* dk, int64_t n_entropy,
+                      int32_t last_seq_len, float entropy_target, const float* entropy, float entropy_upstream,
+                      float* entropy_loss, float* d_entropy, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

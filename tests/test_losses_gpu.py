@@ -79,3 +79,109 @@ def test_fusion_objective_composes():
     total.backward()
     assert torch.isfinite(total) and query.grad is not None and torch.isfinite(query.grad).all()
     assert float(query.grad.abs().sum()) > 0
+
+
+def _nce_reference(q, k, off, T, coef, rows_sel=None, cols_sel=None):
+    """float32 torch reference of one direction on the device, in row chunks (the logits of a chunk only)."""
+    qf, kf = q.float(), k.float()
+    rows, cols = qf.shape[0], kf.shape[0]
+    lse = torch.empty(rows, device=q.device)
+    loss = torch.empty(rows, device=q.device)
+    dq = torch.zeros_like(qf)
+    dk = torch.zeros_like(kf)
+    for r0 in range(0, rows, 1024):
+        r1 = min(r0 + 1024, rows)
+        s = qf[r0:r1] @ kf.T / T
+        lse[r0:r1] = torch.logsumexp(s, dim=1)
+        idx = torch.arange(r0, r1, device=q.device)
+        loss[r0:r1] = lse[r0:r1] - s[idx - r0, off + idx]
+        p = torch.exp(s - lse[r0:r1, None])
+        p[idx - r0, off + idx] -= 1.0
+        p *= coef / T
+        dq[r0:r1] = p @ kf
+        dk += p.T @ qf[r0:r1]
+    return loss, dq, dk
+
+
+@pytest.mark.parametrize("rows,cols,off,d", [(128, 128, 0, 128), (100, 333, 57, 256), (640, 2048, 1000, 512),
+                                             (97, 1500, 3, 768), (64, 700, 600, 1024), (200, 200, 0, 384)])
+def test_flash_nce_matches_float32_reference(rows, cols, off, d):
+    """Streaming InfoNCE (aecf_nce_flash.hip) against float32 torch math on the same bf16 inputs: ragged row / column
+    counts (no % 64 restriction), key splits, every supported width, positives at an offset (a data-parallel shard)."""
+    from aecf_amd.losses import _NceDirection, l2_normalize
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows + cols + d)
+    q = l2_normalize(torch.randn(rows, d, generator=g).to(dev, torch.bfloat16)).detach().requires_grad_(True)
+    k = l2_normalize(torch.randn(cols, d, generator=g).to(dev, torch.bfloat16)).detach()
+    with torch.no_grad():
+        k[off:off + rows] = (0.8 * q.detach().float() + 0.6 * k[off:off + rows].float()).to(torch.bfloat16)   # real positives
+    k.requires_grad_(True)
+    T, coef = 0.07, 0.5 / cols
+    out = _NceDirection.apply(q, k, off, T, coef)
+    out.backward()
+    loss, dq, dk = _nce_reference(q.detach(), k.detach(), off, T, coef)
+    assert abs(float(out) - float(loss.sum() * coef)) < 2e-3 * abs(float(loss.sum() * coef))
+    assert rel_err(q.grad.float().cpu(), dq.cpu()) < 1.5e-2        # P is rounded to bf16 for its MFMA (2^-9 per weight)
+    assert rel_err(k.grad.float().cpu(), dk.cpu()) < 1.5e-2
+
+
+def test_flash_nce_config3_size():
+    """BASELINE configs[2]: 8192 local rows against 65536 gathered keys, d = 768, bf16 -- 2.1 GB of float32 logits that
+    are never materialised (workspace O(rows d): ~50 MB).  Checked against float32 torch math (row-chunked) and, on a
+    row subset, against the CPU oracle's closed form."""
+    from aecf_amd import _lib
+    from aecf_amd.losses import _NceDirection, l2_normalize
+    from oracle import aecf_oracle as O
+    dev = torch.device("cuda:0")
+    rows, cols, d, off, T = 8192, 65536, 768, 3 * 8192, 0.07
+    g = torch.Generator(device=dev).manual_seed(5)
+    q = l2_normalize(torch.randn(rows, d, device=dev, generator=g).to(torch.bfloat16)).detach()
+    k = l2_normalize(torch.randn(cols, d, device=dev, generator=g).to(torch.bfloat16)).detach()
+    k[off:off + rows] = (0.9 * q.float() + 0.45 * k[off:off + rows].float()).to(torch.bfloat16)
+    ws = _lib.load().aecf_nce_workspace_bytes(rows, cols, d, _lib.AECF_BF16)
+    assert ws < 64 << 20, ws                                       # O(rows d), not O(rows cols)
+    q.requires_grad_(True)
+    k.requires_grad_(True)
+    coef = 0.5 / cols
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = _NceDirection.apply(q, k, off, T, coef)
+    out.backward()
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() - base < 1200 << 20   # outputs + gradients + workspace; no logits
+    loss, dq, dk = _nce_reference(q.detach(), k.detach(), off, T, coef)
+    assert abs(float(out) - float(loss.sum() * coef)) < 2e-3 * abs(float(loss.sum() * coef))
+    assert rel_err(q.grad.float(), dq) < 1.5e-2 and rel_err(k.grad.float(), dk) < 1.5e-2
+    # oracle closed form on a row subset (CPU, float64)
+    sel = torch.arange(0, rows, 257)
+    qs, kc = q.detach()[sel].double().cpu(), k.detach().double().cpu()
+    s = qs @ kc.T / T
+    want = torch.logsumexp(s, 1) - s[torch.arange(len(sel)), off + sel]
+    got_rows = (dq[sel].cpu(), None)
+    p = torch.softmax(s, 1)
+    p[torch.arange(len(sel)), off + sel] -= 1.0
+    assert rel_err(q.grad.float()[sel].cpu(), (coef / T) * (p @ kc)) < 1.5e-2
+    assert rel_err(loss[sel].cpu(), want) < 1e-3
+
+
+def test_contrastive_plus_entropy_loss_in_one_call():
+    """north_star "second fused kernel": InfoNCE + entropy_loss with their gradients from one C-ABI call equal the two
+    separate operators."""
+    import aecf_amd
+    from aecf_amd import losses
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    za = torch.randn(256, 256, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    zb = (za.detach().float() * 0.8 + 0.5 * torch.randn(256, 256, generator=g).to(dev)).to(torch.bfloat16).requires_grad_(True)
+    ent = (torch.rand(256, 1, generator=g) * 1.0).to(dev).requires_grad_(True)
+    cm = aecf_amd.CurriculumMasking().to(dev)
+    cm._last_seq_len = 3
+    fused = losses.contrastive_entropy_loss(za, zb, cm, ent, temperature=0.1, entropy_weight=0.5)
+    fused.backward()
+    ga, gb, ge = za.grad.clone(), zb.grad.clone(), ent.grad.clone()
+    za.grad = zb.grad = ent.grad = None
+    sep = losses.info_nce(za, zb, temperature=0.1) + 0.5 * cm.entropy_loss(ent)
+    sep.backward()
+    assert abs(float(fused) - float(sep)) < 1e-3 * abs(float(sep))
+    assert rel_err(ga.float(), za.grad.float()) < 1e-5 and rel_err(gb.float(), zb.grad.float()) < 1e-5
+    assert rel_err(ge, ent.grad) < 1e-5
