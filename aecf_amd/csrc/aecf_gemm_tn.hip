@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs p) {
                 if (ct < nct) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        out[(int64_t)(j0 + j0w + 16 * rt + 4 * lg + r) * E + k0 + k0w + 16 * ct + r16] = acc[rt][ct][r];
+                        if (j0 + j0w + 16 * rt + 4 * lg + r < EJ)         // (EJ need not be a multiple of the wave tile)
+                            out[(int64_t)(j0 + j0w + 16 * rt + 4 * lg + r) * E + k0 + k0w + 16 * ct + r16] = acc[rt][ct][r];
                 }
     }
     // column sums: thread (fg, bg) holds partial sums of its NF features over its batch rows; fold the bg in order

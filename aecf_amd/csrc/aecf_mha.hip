@@ -13,7 +13,16 @@ namespace aecf {
 
 namespace {
 
-constexpr int LMAX = 64;   // tgt_len, src_len <= 64
+constexpr int LMAX = 4096;            // tgt_len, src_len (the score rows of a query chunk live in LDS)
+constexpr int CORE_LDS = 96 * 1024;   // bytes of LDS the attention core uses for its two [rows][S + 1] float arrays
+
+// query rows per block: as many as fit CORE_LDS next to all S keys (at most 64)
+inline int core_rows(int T, int S) {
+    int tc = CORE_LDS / (2 * (S + 1) * (int)sizeof(float));
+    if (tc > 64) tc = 64;
+    if (tc > T) tc = T;
+    return tc < 1 ? 1 : tc;
+}
 
 struct CoreArgs {
     const void* q;        // [B*T,E] projected
@@ -33,29 +42,36 @@ struct CoreArgs {
     void* dq;
     void* dk;
     void* dv;
+    float* dk32;          // [B*S,E] float32 accumulators over the query chunks (only when T > rows per chunk)
+    float* dv32;
     int T, S, E, H;
+    int tc;               // query rows per chunk
     float scale;
 };
 
-// One block per sample.  Per head: scores by wave-level dots, softmax + dropout per row, weighted sum of V.
+// Forward: one block per (sample, chunk of tc query rows).  Per head: scores by wave-level dots against all S keys,
+// softmax + dropout per row, weighted sum of V.  sc / wb: [tc][S + 1] floats in dynamic LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void mha_core_fwd_kernel(CoreArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
-    __shared__ float sc[LMAX][LMAX + 1];
-    __shared__ float wb[LMAX][LMAX + 1];
+    extern __shared__ __attribute__((aligned(16))) char core_smem[];
+    const int Tn = p.T, S = p.S, E = p.E, H = p.H, hd = E / H, SP = S + 1;
+    float* sc = reinterpret_cast<float*>(core_smem);
+    float* wb = sc + p.tc * SP;
     const int64_t b = blockIdx.x;
+    const int t0 = blockIdx.y * p.tc;
+    const int nt = (Tn - t0) < p.tc ? (Tn - t0) : p.tc;
     const int lane = lane_id(), w = wave_id();
-    const int Tn = p.T, S = p.S, E = p.E, H = p.H, hd = E / H;
-    const elem* q = reinterpret_cast<const elem*>(p.q) + b * Tn * (int64_t)E;
+    const elem* q = reinterpret_cast<const elem*>(p.q) + (b * Tn + t0) * (int64_t)E;
     const elem* k = reinterpret_cast<const elem*>(p.k) + b * S * (int64_t)E;
     const elem* v = reinterpret_cast<const elem*>(p.v) + b * S * (int64_t)E;
-    elem* o = reinterpret_cast<elem*>(p.o) + b * Tn * (int64_t)E;
-    for (int i = threadIdx.x; i < Tn * S; i += 256) wb[i / S][i % S] = 0.f;
+    elem* o = reinterpret_cast<elem*>(p.o) + (b * Tn + t0) * (int64_t)E;
+    for (int i = threadIdx.x; i < nt * S; i += 256) wb[(i / S) * SP + i % S] = 0.f;
     const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     for (int h = 0; h < H; ++h) {
         __syncthreads();
-        for (int pair = w; pair < Tn * S; pair += 4) {
+        for (int pair = w; pair < nt * S; pair += 4) {
             const int t = pair / S, s = pair % S;
             float a = 0.f;
             for (int e = lane; e < hd; e += 64)
@@ -63,105 +79,121 @@ __global__ __launch_bounds__(256) void mha_core_fwd_kernel(CoreArgs p) {
             a = reduce_wave(a);
             if (lane == 0) {
                 a *= p.scale;
-                if (p.attn_mask) a += p.attn_mask[(b * H + h) * p.mask_stride + t * S + s];
+                if (p.attn_mask) a += p.attn_mask[(b * H + h) * p.mask_stride + (int64_t)(t0 + t) * S + s];
                 if (p.kpm && p.kpm[b * S + s]) a = -INFINITY;
-                sc[t][s] = a;
+                sc[t * SP + s] = a;
             }
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < Tn; t += 256) {
+        for (int t = threadIdx.x; t < nt; t += 256) {
             float mx = -INFINITY;
-            for (int s = 0; s < S; ++s) mx = fmaxf(mx, sc[t][s]);
+            for (int s = 0; s < S; ++s) mx = fmaxf(mx, sc[t * SP + s]);
             float sum = 0.f;
-            for (int s = 0; s < S; ++s) { const float ex = expf(sc[t][s] - mx); sc[t][s] = ex; sum += ex; }
+            for (int s = 0; s < S; ++s) { const float ex = expf(sc[t * SP + s] - mx); sc[t * SP + s] = ex; sum += ex; }
             for (int s = 0; s < S; ++s) {
-                float pv = sc[t][s] / sum;
-                const int64_t idx = ((b * H + h) * Tn + t) * S + s;
+                float pv = sc[t * SP + s] / sum;
+                const int64_t idx = ((b * H + h) * Tn + t0 + t) * S + s;
                 p.probs[idx] = pv;
                 if (p.drop_p > 0.f) pv = p.drop_u[idx] >= p.drop_p ? pv * keep_scale : 0.f;
-                sc[t][s] = pv;
-                wb[t][s] += pv;
+                sc[t * SP + s] = pv;
+                wb[t * SP + s] += pv;
             }
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < Tn * hd; idx += 256) {
+        for (int idx = threadIdx.x; idx < nt * hd; idx += 256) {
             const int t = idx / hd, e = idx % hd;
             float a = 0.f;
-            for (int s = 0; s < S; ++s) a += sc[t][s] * X::to_f32(v[(int64_t)s * E + h * hd + e]);
+            for (int s = 0; s < S; ++s) a += sc[t * SP + s] * X::to_f32(v[(int64_t)s * E + h * hd + e]);
             o[(int64_t)t * E + h * hd + e] = X::from_f32(a);
         }
     }
     __syncthreads();
     const float invH = 1.0f / (float)H;
-    for (int i = threadIdx.x; i < Tn * S; i += 256) p.attn_w[b * Tn * S + i] = wb[i / S][i % S] * invH;
+    for (int i = threadIdx.x; i < nt * S; i += 256)
+        p.attn_w[(b * Tn + t0) * S + i] = wb[(i / S) * SP + i % S] * invH;
 }
 
+// Backward: one block per sample, looping over the query chunks (dq rows are complete per chunk; dk / dv are sums over
+// all query rows: element (s, e) is owned by one thread, which carries it over the chunks -- in float32 scratch when there
+// is more than one chunk).
 template <typename T>
 __global__ __launch_bounds__(256) void mha_core_bwd_kernel(CoreArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
-    __shared__ float pp[LMAX][LMAX + 1];    // dropped-out weights p'
-    __shared__ float ds[LMAX][LMAX + 1];
+    extern __shared__ __attribute__((aligned(16))) char core_smem[];
+    const int Tn = p.T, S = p.S, E = p.E, H = p.H, hd = E / H, SP = S + 1;
+    float* pp = reinterpret_cast<float*>(core_smem);     // dropped-out weights p'
+    float* ds = pp + p.tc * SP;
     const int64_t b = blockIdx.x;
     const int lane = lane_id(), w = wave_id();
-    const int Tn = p.T, S = p.S, E = p.E, H = p.H, hd = E / H;
-    const elem* q = reinterpret_cast<const elem*>(p.q) + b * Tn * (int64_t)E;
     const elem* k = reinterpret_cast<const elem*>(p.k) + b * S * (int64_t)E;
     const elem* v = reinterpret_cast<const elem*>(p.v) + b * S * (int64_t)E;
-    const elem* dout = reinterpret_cast<const elem*>(p.dout) + b * Tn * (int64_t)E;
-    elem* dq = reinterpret_cast<elem*>(p.dq) + b * Tn * (int64_t)E;
     elem* dk = reinterpret_cast<elem*>(p.dk) + b * S * (int64_t)E;
     elem* dv = reinterpret_cast<elem*>(p.dv) + b * S * (int64_t)E;
+    float* dk32 = p.dk32 ? p.dk32 + b * S * (int64_t)E : nullptr;
+    float* dv32 = p.dv32 ? p.dv32 + b * S * (int64_t)E : nullptr;
     const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const float invH = 1.0f / (float)H;
+    const int nchunk = (Tn + p.tc - 1) / p.tc;
     for (int h = 0; h < H; ++h) {
-        __syncthreads();
-        // dp'[t][s] = dout_h[t] . V_h[s] + d_attn_w[t][s] / H
-        for (int pair = w; pair < Tn * S; pair += 4) {
-            const int t = pair / S, s = pair % S;
-            float a = 0.f;
-            for (int e = lane; e < hd; e += 64)
-                a += X::to_f32(dout[(int64_t)t * E + h * hd + e]) * X::to_f32(v[(int64_t)s * E + h * hd + e]);
-            a = reduce_wave(a);
-            if (lane == 0) {
-                if (p.d_attn_w) a += p.d_attn_w[b * Tn * S + t * S + s] * invH;
-                ds[t][s] = a;
+        for (int ci = 0; ci < nchunk; ++ci) {
+            const int t0 = ci * p.tc;
+            const int nt = (Tn - t0) < p.tc ? (Tn - t0) : p.tc;
+            const elem* q = reinterpret_cast<const elem*>(p.q) + (b * Tn + t0) * (int64_t)E;
+            const elem* dout = reinterpret_cast<const elem*>(p.dout) + (b * Tn + t0) * (int64_t)E;
+            elem* dq = reinterpret_cast<elem*>(p.dq) + (b * Tn + t0) * (int64_t)E;
+            __syncthreads();
+            // dp'[t][s] = dout_h[t] . V_h[s] + d_attn_w[t][s] / H
+            for (int pair = w; pair < nt * S; pair += 4) {
+                const int t = pair / S, s = pair % S;
+                float a = 0.f;
+                for (int e = lane; e < hd; e += 64)
+                    a += X::to_f32(dout[(int64_t)t * E + h * hd + e]) * X::to_f32(v[(int64_t)s * E + h * hd + e]);
+                a = reduce_wave(a);
+                if (lane == 0) {
+                    if (p.d_attn_w) a += p.d_attn_w[(b * Tn + t0 + t) * S + s] * invH;
+                    ds[t * SP + s] = a;
+                }
             }
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < Tn; t += 256) {
-            float dot = 0.f;
-            for (int s = 0; s < S; ++s) {
-                const int64_t idx = ((b * H + h) * Tn + t) * S + s;
-                const float pr = p.probs[idx];
-                float keep = 1.0f;
-                if (p.drop_p > 0.f) keep = p.drop_u[idx] >= p.drop_p ? keep_scale : 0.f;
-                const float dpr = ds[t][s] * keep;              // gradient on the softmax output p
-                pp[t][s] = pr * keep;                           // p' (what multiplied V)
-                ds[t][s] = dpr;
-                dot += pr * dpr;
+            __syncthreads();
+            for (int t = threadIdx.x; t < nt; t += 256) {
+                float dot = 0.f;
+                for (int s = 0; s < S; ++s) {
+                    const int64_t idx = ((b * H + h) * Tn + t0 + t) * S + s;
+                    const float pr = p.probs[idx];
+                    float keep = 1.0f;
+                    if (p.drop_p > 0.f) keep = p.drop_u[idx] >= p.drop_p ? keep_scale : 0.f;
+                    const float dpr = ds[t * SP + s] * keep;        // gradient on the softmax output p
+                    pp[t * SP + s] = pr * keep;                     // p' (what multiplied V)
+                    ds[t * SP + s] = dpr;
+                    dot += pr * dpr;
+                }
+                for (int s = 0; s < S; ++s) {
+                    const int64_t idx = ((b * H + h) * Tn + t0 + t) * S + s;
+                    ds[t * SP + s] = p.probs[idx] * (ds[t * SP + s] - dot) * p.scale;   // gradient on the scaled scores
+                }
             }
-            for (int s = 0; s < S; ++s) {
-                const int64_t idx = ((b * H + h) * Tn + t) * S + s;
-                ds[t][s] = p.probs[idx] * (ds[t][s] - dot) * p.scale;   // gradient on the scaled scores
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < nt * hd; idx += 256) {
+                const int t = idx / hd, e = idx % hd;
+                float a = 0.f;
+                for (int s = 0; s < S; ++s) a += ds[t * SP + s] * X::to_f32(k[(int64_t)s * E + h * hd + e]);
+                dq[(int64_t)t * E + h * hd + e] = X::from_f32(a);
             }
-        }
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < Tn * hd; idx += 256) {
-            const int t = idx / hd, e = idx % hd;
-            float a = 0.f;
-            for (int s = 0; s < S; ++s) a += ds[t][s] * X::to_f32(k[(int64_t)s * E + h * hd + e]);
-            dq[(int64_t)t * E + h * hd + e] = X::from_f32(a);
-        }
-        for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
-            const int s = idx / hd, e = idx % hd;
-            float a = 0.f, c = 0.f;
-            for (int t = 0; t < Tn; ++t) {
-                a += ds[t][s] * X::to_f32(q[(int64_t)t * E + h * hd + e]);
-                c += pp[t][s] * X::to_f32(dout[(int64_t)t * E + h * hd + e]);
+            for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
+                const int s = idx / hd, e = idx % hd;
+                float a = 0.f, c = 0.f;
+                for (int t = 0; t < nt; ++t) {
+                    a += ds[t * SP + s] * X::to_f32(q[(int64_t)t * E + h * hd + e]);
+                    c += pp[t * SP + s] * X::to_f32(dout[(int64_t)t * E + h * hd + e]);
+                }
+                const int64_t o = (int64_t)s * E + h * hd + e;
+                if (nchunk > 1) {
+                    if (ci > 0) { a += dk32[o]; c += dv32[o]; }
+                    if (ci + 1 < nchunk) { dk32[o] = a; dv32[o] = c; }
+                }
+                if (ci + 1 == nchunk) { dk[o] = X::from_f32(a); dv[o] = X::from_f32(c); }
             }
-            dk[(int64_t)s * E + h * hd + e] = X::from_f32(a);
-            dv[(int64_t)s * E + h * hd + e] = X::from_f32(c);
         }
     }
 }
@@ -178,7 +210,7 @@ void nt(int dtype, const void* a, int64_t rows, const void* w, const void* bias,
 }
 
 struct MhaWs {
-    size_t wt[4], dob, dq, dk, dv, slab[4], cs[4], total;
+    size_t wt[4], dob, dq, dk, dv, dk32, dv32, slab[4], cs[4], total;
     int splits[2];
     int64_t rps[2];
 };
@@ -205,6 +237,9 @@ MhaWs mha_layout(const aecf_mha_desc* d) {
     w.dq = off;  off = align_up(off + RT * E * es);
     w.dk = off;  off = align_up(off + RS * E * es);
     w.dv = off;  off = align_up(off + RS * E * es);
+    const bool chunked = core_rows(d->tgt_len, d->src_len) < d->tgt_len;     // float32 carries of dk / dv over the query chunks
+    w.dk32 = off; off = align_up(off + (chunked ? RS * E * 4 : 0));
+    w.dv32 = off; off = align_up(off + (chunked ? RS * E * 4 : 0));
     const int sp[4] = {w.splits[0], w.splits[1], w.splits[1], w.splits[0]};     // q, k, v, out
     for (int i = 0; i < 4; ++i) { w.slab[i] = off; off = align_up(off + (size_t)sp[i] * E * E * 4); }
     for (int i = 0; i < 4; ++i) { w.cs[i] = off; off = align_up(off + (size_t)sp[i] * E * 4); }
@@ -236,7 +271,9 @@ int aecf_mha_check(const aecf_mha_desc* d) {
     if (d->embed_dim % d->num_heads != 0) return AECF_ERR_BAD_DIMS;
     if (d->dtype != AECF_BF16 && d->dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
     if (d->tgt_len > LMAX || d->src_len > LMAX) return AECF_ERR_UNSUPPORTED;
-    if (d->embed_dim % 64 != 0 || d->embed_dim > 1024) return AECF_ERR_UNSUPPORTED;
+    // any head count dividing E; E itself a whole number of 128-byte K slices of the GEMM tiles: a multiple of 32 (f32) /
+    // 64 (bf16) -- E = 32, 96, ... in float32
+    if (d->embed_dim % (d->dtype == AECF_BF16 ? 64 : 32) != 0 || d->embed_dim > 1024) return AECF_ERR_UNSUPPORTED;
     if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return AECF_ERR_BAD_DIMS;
     return AECF_OK;
 }
@@ -266,8 +303,18 @@ int aecf_mha_forward(const aecf_mha_desc* d, const aecf_mha_fwd_args* a, void* s
     c.kpm = a->key_padding_mask; c.drop_u = a->dropout_uniforms; c.drop_p = d->dropout_p; c.o = a->saved_o;
     c.probs = a->saved_probs; c.attn_w = a->attn_w; c.T = d->tgt_len; c.S = d->src_len; c.E = E; c.H = H;
     c.scale = sqrtf(1.0f / (float)(E / H));
-    if (d->dtype == AECF_BF16) mha_core_fwd_kernel<BF16><<<dim3((unsigned)d->batch), dim3(256), 0, s>>>(c);
-    else mha_core_fwd_kernel<F32><<<dim3((unsigned)d->batch), dim3(256), 0, s>>>(c);
+    c.tc = core_rows(d->tgt_len, d->src_len);
+    {
+        const size_t smem = (size_t)2 * c.tc * (d->src_len + 1) * sizeof(float);
+        const dim3 grid((unsigned)d->batch, (unsigned)((d->tgt_len + c.tc - 1) / c.tc));
+        if (d->dtype == AECF_BF16) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_core_fwd_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS + 4096);
+            mha_core_fwd_kernel<BF16><<<grid, dim3(256), smem, s>>>(c);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_core_fwd_kernel<F32>), hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS + 4096);
+            mha_core_fwd_kernel<F32><<<grid, dim3(256), smem, s>>>(c);
+        }
+    }
     nt(d->dtype, a->saved_o, RT, a->w_out, a->b_out, a->y, E, H, s);
     return launch_status();
 }
@@ -301,8 +348,18 @@ int aecf_mha_backward(const aecf_mha_desc* d, const aecf_mha_bwd_args* a, void* 
     c.q = a->saved_q; c.k = a->saved_k; c.v = a->saved_v; c.drop_u = a->dropout_uniforms; c.drop_p = d->dropout_p;
     c.probs = const_cast<float*>(a->saved_probs); c.dout = dob; c.d_attn_w = a->d_attn_w; c.dq = dqb; c.dk = dkb;
     c.dv = dvb; c.T = d->tgt_len; c.S = d->src_len; c.E = E; c.H = H; c.scale = sqrtf(1.0f / (float)(E / H));
-    if (d->dtype == AECF_BF16) mha_core_bwd_kernel<BF16><<<dim3((unsigned)d->batch), dim3(256), 0, s>>>(c);
-    else mha_core_bwd_kernel<F32><<<dim3((unsigned)d->batch), dim3(256), 0, s>>>(c);
+    c.tc = core_rows(d->tgt_len, d->src_len);
+    if (c.tc < d->tgt_len) { c.dk32 = (float*)(ws + L.dk32); c.dv32 = (float*)(ws + L.dv32); }
+    {
+        const size_t smem = (size_t)2 * c.tc * (d->src_len + 1) * sizeof(float);
+        if (d->dtype == AECF_BF16) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_core_bwd_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS + 4096);
+            mha_core_bwd_kernel<BF16><<<dim3((unsigned)d->batch), dim3(256), smem, s>>>(c);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mha_core_bwd_kernel<F32>), hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS + 4096);
+            mha_core_bwd_kernel<F32><<<dim3((unsigned)d->batch), dim3(256), smem, s>>>(c);
+        }
+    }
     nt(d->dtype, dqb, RT, wt[0], nullptr, a->dquery, E, H, s);
     nt(d->dtype, dkb, RS, wt[1], nullptr, a->dkey, E, H, s);
     nt(d->dtype, dvb, RS, wt[2], nullptr, a->dvalue, E, H, s);

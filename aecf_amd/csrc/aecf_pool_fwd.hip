@@ -65,9 +65,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const typename Tr<T>::el
     __shared__ typename Tr<T>::elem tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
-    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(int64_t)(j0 + r) * E + k0 + tx];
+    for (int r = ty; r < 32; r += 8)
+        if (j0 + r < E && k0 + tx < E) tile[r][tx] = src[(int64_t)(j0 + r) * E + k0 + tx];
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) dst[(int64_t)(k0 + r) * E + j0 + tx] = tile[tx][r];
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < E && j0 + tx < E) dst[(int64_t)(k0 + r) * E + j0 + tx] = tile[tx][r];
 }
 
 // All parameter-only preparation in ONE launch (each tiny kernel costs ~5 us of launch/drain on this part):
@@ -177,9 +179,11 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
     if (id >= nt) id -= nt;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int j0 = (id / (E / 32)) * 32, k0 = (id % (E / 32)) * 32;
-    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(int64_t)(j0 + r) * E + k0 + tx];
+    for (int r = ty; r < 32; r += 8)
+        if (j0 + r < E && k0 + tx < E) tile[r][tx] = src[(int64_t)(j0 + r) * E + k0 + tx];
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) dst[(int64_t)(k0 + r) * E + j0 + tx] = tile[tx][r];
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < E && j0 + tx < E) dst[(int64_t)(k0 + r) * E + j0 + tx] = tile[tx][r];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -332,7 +336,7 @@ void launch_prep_all(int dtype, const void* w_in, const void* b_in, const void* 
 }
 
 void launch_transpose(int dtype, const void* src, void* dst, int E, hipStream_t s) {
-    dim3 grid(E / 32, E / 32), block(256);
+    dim3 grid((E + 31) / 32, (E + 31) / 32), block(256);
     if (dtype == 0)
         transpose_kernel<BF16><<<grid, block, 0, s>>>((const unsigned short*)src, (unsigned short*)dst, E);
     else

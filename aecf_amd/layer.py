@@ -445,6 +445,9 @@ class CurriculumMasking(nn.Module):
         _require_device(weights, "weights")
         dt = weights.dtype
         seq_len = weights.size(-1)
+        if seq_len > 32:
+            raise NotImplementedError(f"aecf_amd: CurriculumMasking over {seq_len} keys is not built (the mask kernels keep "
+                                      "a row in registers: up to 32 keys; the reference's callers use 2-4 modalities)")
         if not self.training:                                                 # ref :150-156
             _, entropy, mask_rate = _MaskFunction.apply(weights, None, 2, self.min_active,
                                                         float(self.base_mask_prob), float(self.entropy_target), 1e-8)
@@ -614,7 +617,8 @@ class MultimodalAttentionPool(nn.Module):
         # not MFMA K-step multiples) are served by the general kernels as long as THEY take them
         fast_ok = _lib.load().aecf_pool_check(ctypes.byref(_lib.PoolDesc(
             batch_size, src_len, embed_dim, self.num_heads, _DTYPES[key.dtype], 0, 1, 0.15, 0.7, 1e-8))) == 0
-        general_ok = src_len <= 64 and tgt_len <= 64 and embed_dim % 64 == 0 and embed_dim <= 1024
+        general_ok = _lib.load().aecf_mha_check(ctypes.byref(_lib.MhaDesc(
+            batch_size, tgt_len, src_len, embed_dim, self.num_heads, _DTYPES[key.dtype], 0.0))) == 0
         float_kpm = key_padding_mask is not None and key_padding_mask.is_floating_point()   # additive in torch
         if (q_base is None or not same_kv or attn_mask is not None or dropping or float_kpm
                 or (not fast_ok and general_ok)):

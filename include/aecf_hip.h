@@ -226,13 +226,14 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
  *   per (b,h): p = softmax(Q_h K_h^T / sqrt(hd) + attn_mask, key_padding_mask -> -inf); p' = dropout(p)
  *   o_h = p' V_h ;  y = o W_o^T + b_o ;  attn_w = mean_h p'   (the weights are returned AFTER dropout, as torch does)
  * Dropout takes explicit uniforms: keep = (u >= dropout_p), p' = p * keep / (1 - dropout_p)  (torch draws its own
- * Philox stream inside F.dropout, so the pattern is distribution-, not bit-, compatible).  tgt_len, src_len <= 64. */
+ * Philox stream inside F.dropout, so the pattern is distribution-, not bit-, compatible).  tgt_len, src_len <= 4096 (the
+ * score rows of a chunk of query positions live in LDS; longer targets are walked in chunks). */
 typedef struct aecf_mha_desc {
     int64_t batch;
     int32_t tgt_len;      /* T */
     int32_t src_len;      /* S */
-    int32_t embed_dim;    /* E, multiple of 64, <= 1024 */
-    int32_t num_heads;    /* H, E % H == 0 */
+    int32_t embed_dim;    /* E <= 1024, multiple of 32 (f32) / 64 (bf16) */
+    int32_t num_heads;    /* H, any divisor of E */
     int32_t dtype;        /* aecf_dtype of activations and weights */
     float dropout_p;      /* 0 = no dropout (then dropout_uniforms may be NULL) */
 } aecf_mha_desc;

@@ -123,3 +123,63 @@ def test_general_path_with_curriculum_masking_info_contract():
     m = O.curriculum_mask_train(info["attention_weights"].detach().cpu(), U, 0.3)
     assert torch.equal((info["masked_attention_weights"] != 0).cpu(), m["masked"] != 0)
     assert cm._last_seq_len == M
+
+
+def test_functional_slow_path_matches_reference_g7():
+    """SURVEY 8a row A8, ref aecf/AECFLayer.py:643-652: anything but the projection-free fast path builds a FRESH randomly
+    initialised module per call (CPU generator state at call time) and runs it.  Fixtures g7 slow_seed71_h4 (E = 32, 4
+    heads of 8, eval) and slow_seed72_train (2 heads, training-mode curriculum masking, value = None) are the
+    reference's outputs under those seeds."""
+    import aecf_amd
+    g = load_npz("g7_functional.npz")
+    q, k, v = (torch.from_numpy(g[n]).to(DEV) for n in ("q", "k", "v"))
+    torch.manual_seed(71)
+    out = aecf_amd.multimodal_attention_pool(q, k, v, num_heads=4)
+    assert rel_err(out.cpu(), g["slow_seed71_h4"]) < 1e-5
+    torch.manual_seed(72)
+    out = aecf_amd.multimodal_attention_pool(q[:, :1], k, None, num_heads=2,
+                                             curriculum_masking=aecf_amd.CurriculumMasking(0.3).to(DEV), training=True)
+    assert rel_err(out.cpu(), g["slow_seed72_train"]) < 1e-5
+
+
+@pytest.mark.parametrize("E,H,B,T,S,dtype,tol", [
+    (32, 4, 5, 2, 5, torch.float32, 1e-5),         # head_dim 8
+    (96, 3, 4, 3, 7, torch.float32, 1e-5),         # E % 64 != 0
+    (192, 6, 3, 2, 4, torch.bfloat16, 1e-2),       # bf16, 6 heads of 32
+    (64, 2, 2, 100, 150, torch.float32, 1e-5),     # tgt_len, src_len > 64: one query chunk, long rows
+    (64, 4, 2, 200, 700, torch.float32, 2e-5),     # several query chunks: dk / dv carried over the chunks
+])
+def test_general_path_reach(E, H, B, T, S, dtype, tol):
+    """nn.MultiheadAttention accepts any embed_dim divisible by num_heads and any sequence lengths
+    (ref aecf/AECFLayer.py:384-391); so does the general path -- against the oracle, forward and backward."""
+    import aecf_amd
+    from oracle import aecf_oracle as O
+    g = torch.Generator().manual_seed(E + T + S)
+    pool = aecf_amd.MultimodalAttentionPool(E, num_heads=H)
+    with torch.no_grad():
+        pool.attention.in_proj_bias.normal_(0, 0.1, generator=g)
+        pool.attention.out_proj.bias.normal_(0, 0.1, generator=g)
+        if dtype == torch.bfloat16:
+            for prm in pool.parameters():
+                prm.copy_(prm.to(dtype).float())
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(dtype).float()
+    q, k, v, dy, dw = rnd(B, T, E), rnd(B, S, E), rnd(B, S, E), rnd(B, T, E), rnd(B, T, S)
+    kpm = torch.rand(B, S, generator=g) < 0.2
+    kpm[:, 0] = False
+    a = pool.attention
+    w = [t_.detach().clone() for t_ in (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias)]
+    f = O.mha_forward(q, k, v, w[0], w[1], w[2], w[3], H, kpm)
+    b = O.mha_backward(q, k, v, w[0], w[1], w[2], H, f, dy, dw)
+    pool = pool.to(DEV, dtype).eval()
+    qd, kd, vd = (t_.to(DEV, dtype).requires_grad_(True) for t_ in (q, k, v))
+    y, info = pool(qd, kd, vd, key_padding_mask=kpm.to(DEV), return_info=True)
+    ((y.float() * dy.to(DEV)).sum() + (info["attention_weights"].float() * dw.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    cpu = lambda t_: t_.detach().float().cpu()
+    got = dict(y=cpu(y), wbar=cpu(info["attention_weights"]), dquery=cpu(qd.grad), dkey=cpu(kd.grad), dvalue=cpu(vd.grad),
+               dw_in=cpu(pool.attention.in_proj_weight.grad), db_in=cpu(pool.attention.in_proj_bias.grad),
+               dw_out=cpu(pool.attention.out_proj.weight.grad), db_out=cpu(pool.attention.out_proj.bias.grad))
+    want = dict(y=f["y"], wbar=f["wbar"], dquery=b["dquery"], dkey=b["dkey"], dvalue=b["dvalue"], dw_in=b["dw_in"],
+                db_in=b["db_in"], dw_out=b["dw_out"], db_out=b["db_out"])
+    for k_ in want:
+        assert rel_err(got[k_], want[k_]) < tol, (k_, rel_err(got[k_], want[k_]))

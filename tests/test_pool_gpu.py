@@ -424,14 +424,17 @@ def test_unsupported_configurations_fail_loudly():
     x = torch.randn(4, 3, 64, device=dev)
     pool = aecf_amd.MultimodalAttentionPool(64, num_heads=2).to(dev)
     with pytest.raises(RuntimeError, match="not supported"):                    # src_len beyond the general kernels
-        pool(torch.randn(4, 2, 64, device=dev), torch.randn(4, 65, 64, device=dev))
+        pool(torch.randn(4, 2, 64, device=dev), torch.randn(4, 5000, 64, device=dev))
     with pytest.raises(RuntimeError, match="2D attn_mask"):
         pool(torch.randn(4, 2, 64, device=dev), x, attn_mask=torch.zeros(3, 3, device=dev))
     with pytest.raises(NotImplementedError):
         pool(torch.randn(4, 1, 64, device=dev).double(), x.double())            # float64 is not built
-    pool96 = aecf_amd.MultimodalAttentionPool(96, num_heads=2).to(dev)          # E not a multiple of 64: no kernel takes it
+    pool40 = aecf_amd.MultimodalAttentionPool(40, num_heads=2).to(dev)          # E not a multiple of 32: no kernel takes it
     with pytest.raises(RuntimeError, match="not supported"):
-        pool96(torch.randn(1, 1, 96, device=dev).expand(4, -1, -1), torch.randn(4, 3, 96, device=dev))
+        pool40(torch.randn(1, 1, 40, device=dev).expand(4, -1, -1), torch.randn(4, 3, 40, device=dev))
+    cm = aecf_amd.CurriculumMasking().to(dev).train()
+    with pytest.raises(NotImplementedError, match="32 keys"):                   # the mask kernels keep a row in registers
+        cm(torch.softmax(torch.randn(4, 1, 40, device=dev), -1))
 
 
 def test_shapes_outside_the_shared_query_kernels_use_the_general_path():
