@@ -99,7 +99,7 @@ struct RowFwdCfg {
 };
 
 template <int NW, int M_, int ST>
-__global__ __launch_bounds__(512, 2) void row_fwd_kernel(RowFwdArgs p, int ntile, int dbg) {
+__global__ __launch_bounds__(512, 2) void row_fwd_kernel(RowFwdArgs p, int ntile) {
     using C = RowFwdCfg<NW, M_, ST>;
     using X = Tr<BF16>;
     constexpr int E = C::E, KT = C::KT, TS = C::TS, XT = C::XT;
@@ -135,7 +135,6 @@ __global__ __launch_bounds__(512, 2) void row_fwd_kernel(RowFwdArgs p, int ntile
 
     // chunk stream: (tile, phase 0 = W_v + x | phase 1 = W_o, chunk c) -> ring slot
     auto issue = [&](int tile, int phase, int c, int slot) {
-        if (dbg & 2) return;
         char* dst = smem + slot * C::SLOT;
         const char* wsrc = reinterpret_cast<const char*>(phase == 0 ? p.w_v : p.w_o);
 #pragma unroll
@@ -197,7 +196,6 @@ __global__ __launch_bounds__(512, 2) void row_fwd_kernel(RowFwdArgs p, int ntile
                         }
                 }
             }
-            if (dbg & 1) continue;
             const char* ws = smem + (c & 1) * C::SLOT;
             const char* xs = ws + C::WSLOT;
             u32x4 bf[XT];
@@ -347,7 +345,6 @@ __global__ __launch_bounds__(512, 2) void row_fwd_kernel(RowFwdArgs p, int ntile
             block_sync();
             if (c + 1 < KT) issue(tile, 1, c + 1, (c + 1) & 1);
             else if (more) issue(tile + (int)gridDim.x, 0, 0, 0);
-            if (dbg & 1) continue;
             const char* ws = smem + (c & 1) * C::SLOT;
             const char* ot = smem + C::OFF_O + c * (TS * 64);
             u32x4 bo[ST];
@@ -397,8 +394,7 @@ void launch_row_fwd_t(const RowFwdArgs& a, hipStream_t s) {
     if (grid > ntile) grid = ntile;
     auto kern = row_fwd_kernel<NW, M_, ST>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
-    static const int dbg = getenv("AECF_ROWDBG") ? atoi(getenv("AECF_ROWDBG")) : 0;
-    kern<<<dim3(grid), dim3(512), C::TOTAL, s>>>(a, ntile, dbg);
+    kern<<<dim3(grid), dim3(512), C::TOTAL, s>>>(a, ntile);
 }
 
 }  // namespace

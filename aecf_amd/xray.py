@@ -230,6 +230,14 @@ class AECFModel(nn.Module):
 
         info: Dict[str, torch.Tensor] = {}
         if route.counts[BOTH] > 0:
+            if mask_uniforms is not None and mask_uniforms.shape[0] == route.rows != route.counts[BOTH]:
+                # uniforms given per BATCH row (a data-parallel step hands every rank its rows of one global tensor):
+                # compact them like the features, so that a row's mask does not depend on how the batch was sharded
+                mu = mask_uniforms.detach().to(device=enc_a.device, dtype=torch.float32).reshape(route.rows, -1).contiguous()
+                cu = torch.empty(route.counts[BOTH], mu.shape[1], dtype=torch.float32, device=mu.device)
+                _rows_gather([(mu, mu.shape[1] * 4, route.index(BOTH), cu.data_ptr(), mu.shape[1] * 4, route.counts[BOTH])],
+                             mu.shape[1] * 4)
+                mask_uniforms = cu
             pairs = _PairGather.apply(enc_a, enc_b, route)
             pooled, pool_info = self.attention_pool(self.fusion_query.expand(route.counts[BOTH], -1, -1), pairs, pairs,
                                                     return_info=True, uniforms=mask_uniforms, generator=generator)

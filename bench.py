@@ -127,21 +127,23 @@ class StageTimer:
 
 
 def stage_model(cfg):
-    """Algorithmic HBM bytes and MFMA flops per sample of each stage."""
+    """Algorithmic HBM bytes and executed MFMA flops per sample of each stage.  "Algorithmic" =
+    SURVEY 8d's share of that stage: the path inputs it must read and the outputs it exists to produce -- tensors kept
+    only to spare the backward a recompute are traffic (roofline.traffic shows them), not algorithm."""
     B, M, E, H, dtype, _ = cfg
     s = 2 if dtype == torch.bfloat16 else 4
+    ku = (16 * M + 31) // 32
     return {
         "fwd.gate":    dict(bytes=s * M * E, flops=2 * M * E * 16 * (2 if s == 2 else 1)),
-        # reads x, writes o.  (The V it also stores for the backward is NOT algorithmic: SURVEY 8d "recompute instead of
-        # saving K/V"; it shows up in roofline.traffic.)
-        "fwd.vproj":   dict(bytes=s * (M + 1) * E, flops=2 * M * E * E),
+        "fwd.vproj":   dict(bytes=s * (M + 1) * E, flops=2 * M * E * E + 2 * M * E * 16 * 2),   # x -> o (scores fused)
         "fwd.outproj": dict(bytes=s * 2 * E, flops=2 * E * E),
         "bwd.dout":    dict(bytes=s * 2 * E, flops=2 * E * E),
         "bwd.dw_out":  dict(bytes=s * 2 * E, flops=2 * E * E),
-        "bwd.dscore":  dict(bytes=s * (M + 1) * E, flops=2 * E * E),
+        # score gradient + u = ds^T x from (do, x): P = W_v^T do per head (one E x E product), u by MFMA on the tile
+        "bwd.dscore":  dict(bytes=s * (M + 1) * E, flops=2 * E * E + 2 * E * 16 * 2 * 2 * ku),
         "bwd.dx":      dict(bytes=s * (M + 1) * E, flops=2 * E * E),
         "bwd.dw_v":    dict(bytes=s * (M + 1) * E, flops=2 * E * E),
-        "bwd.u":       dict(bytes=s * M * E, flops=0),                        # u = ds^T x on the vector ALU, x read once
+        "bwd.u":       dict(bytes=s * M * E, flops=0),          # separate pass only on shapes the fused kernel does not take
     }
 
 
@@ -175,8 +177,31 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         one()
         best = min(best, time.perf_counter() - t0)
         reps += 1
-    return dict(value=n / best, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} samples of the same [B,M={M},d={E}] workload, fp32, fwd+bwd, best of {reps}")
+    out = dict(value=n / best, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"{n} samples of the same [B,M={M},d={E}] workload, fp32, fwd+bwd, best of {reps}")
+    # bf16 leg (what torch's CPU bf16 kernels make of the same arithmetic): a few repetitions, bounded
+    try:
+        bf = torch.bfloat16
+        xb, qb, wib, bib, wob, bob, dyb = (t_.to(bf) for t_ in (x, q, w_in, b_in, w_out, b_out, dy))
+
+        def one_bf16():
+            qe = qb.expand(n, -1, -1)
+            f = O.mha_forward(qe, xb, xb, wib, bib, wob, bob, H)
+            O.mha_backward(qe, xb, xb, wib, bib, wob, H, f, dyb, None)
+
+        one_bf16()
+        best_b, t_all = 1e30, time.perf_counter()
+        for _ in range(5):
+            t0 = time.perf_counter()
+            one_bf16()
+            best_b = min(best_b, time.perf_counter() - t0)
+            if time.perf_counter() - t_all > 8.0:
+                break
+        out["value_bf16"] = n / best_b
+    except Exception as e:                      # a CPU without usable bf16 kernels: the fp32 leg stands alone
+        out["value_bf16"] = None
+        out["bf16_note"] = str(e)[:80]
+    return out
 
 
 def spawn_ranks(n, argv):
