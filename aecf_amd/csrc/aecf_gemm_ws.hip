@@ -773,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" : "+v"(pmv), "+v"(dwb));
-        if (w < HBL) {                                             // whole waves: the lane-group sum below needs every lane
+        if (w < HBL) {                               // whole waves: the lane-group sum below needs every lane
             float da = 0.f;
             if (ds_m < M_) {
                 const float* pr = part + (ds_hh * M_ + ds_m) * 16 + ds_s;

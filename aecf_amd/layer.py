@@ -71,6 +71,24 @@ def _require_device(t: torch.Tensor, what: str) -> None:
 # compare against the backward's own preparation stage
 _SHARE_PREP = True
 
+# what the library answers per call shape (status of aecf_pool_check, workspace sizes, whether the backward wants V):
+# pure functions of the description, asked once per shape instead of on every call (each ctypes round trip is ~1-2 us of a
+# host-bound step at small batches)
+_shape_facts: Dict[Tuple, Tuple] = {}
+
+
+def _pool_facts(lib, desc, key):
+    f = _shape_facts.get(key)
+    if f is None:
+        ref = ctypes.byref(desc)
+        status = lib.aecf_pool_check(ref)
+        f = (status,) if status != 0 else (0, lib.aecf_pool_fwd_workspace_bytes(ref), lib.aecf_pool_bwd_workspace_bytes(ref),
+                                           lib.aecf_pool_prep_bytes(ref), bool(lib.aecf_pool_wants_saved_v(ref)))
+        if len(_shape_facts) > 256:
+            _shape_facts.clear()
+        _shape_facts[key] = f
+    return f
+
 
 class _PoolFunction(torch.autograd.Function):
     """aecf_pool_forward / aecf_pool_backward.  Outputs: y [B,E], attn_w [B,M], masked_w [B,M], entropy [B],
@@ -86,7 +104,9 @@ class _PoolFunction(torch.autograd.Function):
         dt = x.dtype
         desc = _lib.PoolDesc(B, M, E, num_heads, _DTYPES[dt], mask_mode, min_active, base_mask_prob,
                              entropy_target, eps)
-        _lib.check(lib.aecf_pool_check(ctypes.byref(desc)), "aecf_pool_check")
+        facts = _pool_facts(lib, desc, (B, M, E, num_heads, dt, mask_mode))
+        _lib.check(facts[0], "aecf_pool_check")
+        _, fwd_ws_bytes, bwd_ws_bytes, prep_bytes, wants_v = facts
         xc = x.contiguous()
         qc = q.detach().reshape(E).to(dt).contiguous()
         if casts is not None:                  # activation-dtype copies of master weights, cached by the module
@@ -103,11 +123,9 @@ class _PoolFunction(torch.autograd.Function):
         saved_o = torch.empty(B, E, dtype=dt, device=dev)
         # per-modality value projections, kept only when a backward will follow (B*M*E elements)
         need_bwd = any(t is not None and t.requires_grad for t in (x, q, w_in, b_in, w_out, b_out))
-        saved_v = (torch.empty(B, M, E, dtype=dt, device=dev)
-                   if (need_bwd and lib.aecf_pool_wants_saved_v(ctypes.byref(desc))) else None)
+        saved_v = torch.empty(B, M, E, dtype=dt, device=dev) if (need_bwd and wants_v) else None
         # what the backward derives from the parameters alone is produced by the forward's preparation launch
-        saved_prep = (torch.empty(lib.aecf_pool_prep_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
-                      if (need_bwd and _SHARE_PREP) else None)
+        saved_prep = torch.empty(prep_bytes, dtype=torch.uint8, device=dev) if (need_bwd and _SHARE_PREP) else None
         if mask_mode != 0:
             masked_w = torch.empty(B, M, dtype=torch.float32, device=dev)
             entropy = torch.empty(B, dtype=torch.float32, device=dev)
@@ -124,7 +142,7 @@ class _PoolFunction(torch.autograd.Function):
             i_attn_w = i_masked_w = i_entropy = i_mask_rate = None
         # info['target_entropy'] (ref :273), filled by the kernel that writes the other info tensors
         i_target = torch.empty(B, dtype=dt, device=dev) if (mask_mode == 1 and target_value is not None) else None
-        ws_bytes = lib.aecf_pool_fwd_workspace_bytes(ctypes.byref(desc))
+        ws_bytes = fwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolFwdArgs(
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(b_out_c), _ptr(kpm),
@@ -136,6 +154,7 @@ class _PoolFunction(torch.autograd.Function):
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
         ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep)
         ctx.desc = desc
+        ctx.bwd_ws_bytes = bwd_ws_bytes
         ctx.q_shape = q.shape
         ctx.param_dtypes = (q.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
                             None if b_out is None else b_out.dtype)
@@ -173,7 +192,7 @@ class _PoolFunction(torch.autograd.Function):
         flat = torch.empty(4 * E * E + 5 * E, dtype=gdt, device=dev)
         dquery, dw_in, db_in, dw_out, db_out = flat.split([E, 3 * E * E, 3 * E, E * E, E])
         dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
-        ws_bytes = lib.aecf_pool_bwd_workspace_bytes(ctypes.byref(desc))
+        ws_bytes = ctx.bwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolBwdArgs(
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(dy_c), _ptr(daw), _ptr(dent),
@@ -615,9 +634,13 @@ class MultimodalAttentionPool(nn.Module):
         dropping = self.attention.dropout > 0.0 and self.training
         # shapes the shared-query kernels do not take (more than 8 modalities, more than 16 heads, head sizes that are
         # not MFMA K-step multiples) are served by the general kernels as long as THEY take them
-        fast_ok = _lib.load().aecf_pool_check(ctypes.byref(_lib.PoolDesc(
-            batch_size, src_len, embed_dim, self.num_heads, _DTYPES[key.dtype], 0, 1, 0.15, 0.7, 1e-8))) == 0
-        general_ok = _lib.load().aecf_mha_check(ctypes.byref(_lib.MhaDesc(
+        fkey = (batch_size, src_len, embed_dim, self.num_heads, key.dtype, 0)
+        facts = _shape_facts.get(fkey)
+        if facts is None:
+            facts = _pool_facts(_lib.load(), _lib.PoolDesc(batch_size, src_len, embed_dim, self.num_heads, _DTYPES[key.dtype],
+                                                           0, 1, 0.15, 0.7, 1e-8), fkey)
+        fast_ok = facts[0] == 0
+        general_ok = fast_ok or _lib.load().aecf_mha_check(ctypes.byref(_lib.MhaDesc(
             batch_size, tgt_len, src_len, embed_dim, self.num_heads, _DTYPES[key.dtype], 0.0))) == 0
         float_kpm = key_padding_mask is not None and key_padding_mask.is_floating_point()   # additive in torch
         if (q_base is None or not same_kv or attn_mask is not None or dropping or float_kpm

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Regenerates the per-round artefacts under gpurun_out/ on an MI355X box (copy the ones to keep into profiles/):
+#   tools/profile_round.sh r02     -> gpurun_out/r02_{c2,c3,c5}_{bench.json,traffic.json}, r02_c2_kernel_stats.csv
+# rocprofv3 counter passes are separate runs (FETCH_SIZE / WRITE_SIZE do not fit one pass), kernel-trace only.
+set -o pipefail
+tag=${1:-r02}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+out=gpurun_out
+mkdir -p $out
+for cfg in c2 c3 c5; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pf_$cfg -o pmc -- python3 bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pw_$cfg -o pmc -- python3 bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  python3 tools/traffic_from_pmc.py $out/pf_$cfg $out/pw_$cfg $cfg $out/${tag}_${cfg}_traffic.json > /dev/null
+  cp $out/${tag}_${cfg}_traffic.json profiles/${tag}_${cfg}_traffic.json      # bench.py reads roofline.traffic from here
+  echo "traffic $cfg done"
+done
+rocprofv3 --kernel-trace --stats -d $out/ks -o r -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python3 tools/kernel_stats_from_db.py $out/ks/r_results.db $out/${tag}_c2_kernel_stats.csv | head -16
+python3 bench.py --steps 50 --warmup 10 > $out/${tag}_c2_bench.json 2> /dev/null
+python3 bench.py --config c3 --steps 50 --warmup 10 --no-cpu-baseline > $out/${tag}_c3shard_bench.json 2> /dev/null
+python3 bench.py --config c5 --steps 50 --warmup 10 --no-cpu-baseline > $out/${tag}_c5shard_bench.json 2> /dev/null
+for f in c2 c3shard c5shard; do python3 -c "
+import json; l=json.load(open('$out/${tag}_${f}_bench.json')); r=l['roofline']
+print('$f', round(l['ms_per_step'],4), round(l['value']/1e6,1), 'M/s', r['kernel'], round(r['frac'],3), r['traffic'], round(l['path_hbm_frac'],3), round(l['path_mfma_frac'],3))"; done
