@@ -21,6 +21,9 @@ CONFIGS = {
     "c3_shard": (8192, 2, 768, 8, 1024),
     "c5_shard": (16384, 4, 1024, 8, 768),
     "c4_pool": (4096, 2, 256, 4, 1024),
+    # BASELINE configs[4] / configs[2] at their FULL batch on one GPU (they fit: 1.07 GB / 0.2 GB of inputs)
+    "c5_full": (131072, 4, 1024, 8, 512),
+    "c3_full": (65536, 2, 768, 8, 1024),
 }
 
 
