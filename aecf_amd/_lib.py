@@ -11,7 +11,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
                     c_uint8, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaecf_hip.so")
+# AECF_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
+LIB_PATH = os.environ.get("AECF_LIB_PATH") or os.path.join(_HERE, "lib", "libaecf_hip.so")
 
 AECF_ABI_VERSION = 4
 AECF_BF16 = 0
