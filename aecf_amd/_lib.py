@@ -65,7 +65,7 @@ class PoolBwdArgs(Structure):
         ("dquery", c_void_p), ("dw_in", c_void_p), ("db_in", c_void_p), ("dw_out", c_void_p),
         ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
-        ("grad_dtype", c_int32), ("flags", c_int32), ("saved_prep", c_void_p),
+        ("grad_dtype", c_int32), ("flags", c_int32), ("saved_prep", c_void_p), ("out_grads_event", c_void_p),
     ]
 
 

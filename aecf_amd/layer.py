@@ -71,6 +71,11 @@ def _require_device(t: torch.Tensor, what: str) -> None:
 # compare against the backward's own preparation stage
 _SHARE_PREP = True
 
+# Data-parallel overlap hook (aecf_amd/dp.py: GradOverlap): when set, the backward asks the library to announce (a HIP
+# event) the moment dW_o / db_o are final and hands the hook that event together with the tail of the gradient allocation
+# that holds them, so that their all-reduce can start behind the rest of the backward.  None = off.
+_out_grads_hook = None
+
 # what the library answers per call shape (status of aecf_pool_check, workspace sizes, whether the backward wants V):
 # pure functions of the description, asked once per shape instead of on every call (each ctypes round trip is ~1-2 us of a
 # host-bound step at small batches)
@@ -194,13 +199,19 @@ class _PoolFunction(torch.autograd.Function):
         dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
         ws_bytes = ctx.bwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        hook, early = _out_grads_hook, None
+        if hook is not None:
+            early = torch.cuda.Event()
+            early.record()                         # (creates the underlying hipEvent; the library records it again later)
         args = _lib.PoolBwdArgs(
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(dy_c), _ptr(daw), _ptr(dent),
             _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
             _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes,
             None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd),
-            _DTYPES[gdt], 0, _ptr(saved_prep))
+            _DTYPES[gdt], 0, _ptr(saved_prep), None if early is None else early.cuda_event)
         _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")
+        if hook is not None:
+            hook(flat[E + 3 * E * E + 3 * E:], early)      # [dw_out | db_out]: final once `early` has fired
         needs = ctx.needs_input_grad
         return (dx if needs[0] else None,
                 dquery.to(qd).reshape(ctx.q_shape) if needs[1] else None,

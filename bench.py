@@ -62,20 +62,26 @@ def make_inputs(cfg, device, seed_offset=0):
     return pool, query, x, dy
 
 
-def step(pool, query, x, dy, params, dp_on, uniforms=None):
-    """One pass of the hot path over one resident batch: forward (+ entropy_loss) + backward (+ the one
-    gradient all-reduce when data-parallel)."""
+def step(pool, query, x, dy, params, dp_on, uniforms=None, overlap=None):
+    """One pass of the hot path over one resident batch: forward (+ entropy_loss) + backward (+ the gradient all-reduce
+    when data-parallel: the out-projection gradients' collective starts behind the rest of the backward, dp.GradOverlap;
+    --no-overlap: one collective after the backward)."""
     B = x.shape[0]
     out, info = pool(query.expand(B, -1, -1), x, return_info=True, uniforms=uniforms)
     ent_loss = pool.curriculum_masking.entropy_loss(info["entropy"])
     x.grad = None
     for p in params:
         p.grad = None
-    torch.autograd.backward([out], [dy])
-    if dp_on:
-        # ONE RCCL all-reduce (AVG) of the 4E^2+5E values, in place over the allocation the backward wrote them into
-        from aecf_amd.dp import all_reduce_grads
-        all_reduce_grads(params)
+    if dp_on and overlap is not None:
+        with overlap:
+            torch.autograd.backward([out], [dy])
+            overlap.finish(params)
+    else:
+        torch.autograd.backward([out], [dy])
+        if dp_on:
+            # ONE RCCL all-reduce (AVG) of the 4E^2+5E values, in place over the allocation the backward wrote them into
+            from aecf_amd.dp import all_reduce_grads
+            all_reduce_grads(params)
     return out, ent_loss
 
 
@@ -243,6 +249,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = B per GPU fixed (default), strong = the config's B is the GLOBAL batch, sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: one gradient all-reduce after the backward")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -279,12 +286,13 @@ def main():
         dp.probe_avg_support(params[0].dtype, device)
     # curriculum-mask uniforms: every rank draws the SAME global tensor (shared seed, own generator) and uses its rows
     ugen = torch.Generator(device=device).manual_seed(1234) if world > 1 else None
+    overlap = dp.GradOverlap() if (world > 1 and not args.no_overlap) else None
 
     def one_step():
         u = None
         if ugen is not None:
             u = torch.rand(B_global, 1, M, device=device, dtype=torch.float32, generator=ugen)[lo:lo + B]
-        return step(pool, query, x, dy, params, world > 1, u)
+        return step(pool, query, x, dy, params, world > 1, u, overlap)
 
     def barrier():
         if world > 1:
@@ -364,7 +372,9 @@ def main():
             "config": {"workload": f"{args.config}: [B={B} per GPU, M={M}, d={E}, {H} heads] mask_prob={p} "
                                    "train-mode curriculum masking, fwd+bwd", "global_batch": B_global,
                        "parallelism": f"dp{world}", "world_size": world,
-                       "collectives": None if world == 1 else f"{backend}: 1 all-reduce of {4 * E * E + 5 * E} grads/step"},
+                       "collectives": None if world == 1 else (
+                           f"{backend}: all-reduce of {4 * E * E + 5 * E} grads/step" +
+                           (" (out-projection part started behind the backward)" if overlap is not None else " (one call)"))},
             "roofline": roofline,
             "path_hbm_frac": path_bytes * B / sec / 1e9 / HBM_PEAK_GBS,
             "path_mfma_frac": path_flops * B / sec / 1e12 / MFMA_PEAK_TFLOPS,

@@ -156,6 +156,11 @@ typedef struct aecf_pool_bwd_args {
     int32_t grad_dtype;
     int32_t flags;               /* AECF_PRECISE: dy bf16; saved_o, dx and the gradients float32 (see aecf_pool_fwd_args.flags) */
     const void* saved_prep;      /* buffer filled by aecf_pool_forward (see aecf_pool_fwd_args.saved_prep) or NULL */
+    /* optional hipEvent_t (caller-created): recorded on `stream` as soon as dw_out and db_out are FINAL -- after the third
+     * backward stage, with the score gradient, dx and dW_v still to come -- so that a data-parallel caller can start
+     * their all-reduce on another stream behind the rest of the backward (aecf_amd/dp.py: GradOverlap).  Costs one
+     * extra small launch (their slab reduction leaves the final reduction).  NULL = off. */
+    void* out_grads_event;
 } aecf_pool_bwd_args;
 
 #define AECF_FWD_STAGES 4   /* prep, gate, vproj, outproj */

@@ -79,6 +79,17 @@ def _worker(rank, world, port, backend, dtype, q):
         out, masked, dx = _run_shard(query, pool, x[lo:hi], dy[lo:hi], u, dev, float(world))
         dp.all_reduce_grads(params)
         torch.cuda.synchronize()
+        plain = [p.grad.clone() for p in params]
+        # the same step with the out-projection gradients' all-reduce started behind the rest of the backward
+        for p in params:
+            p.grad = None
+        overlap = dp.GradOverlap()
+        with overlap:
+            _run_shard(query, pool, x[lo:hi], dy[lo:hi], u, dev, float(world))
+            overlap.finish(params)
+        torch.cuda.synchronize()
+        for a_, b_ in zip(plain, [p.grad for p in params]):
+            assert torch.equal(a_, b_), "overlapped all-reduce differs from the single collective"
         q.put((rank, lo, hi, out.float().cpu().numpy(), masked.float().cpu().numpy(), dx.float().cpu().numpy(),
                [p.grad.float().cpu().numpy() for p in params], [p.detach().float().cpu().numpy() for p in params]))
     finally:
