@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AECF_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
 LIB_PATH = os.environ.get("AECF_LIB_PATH") or os.path.join(_HERE, "lib", "libaecf_hip.so")
 
-AECF_ABI_VERSION = 4
+AECF_ABI_VERSION = 5
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_PRECISE = 1
@@ -65,7 +65,7 @@ class PoolBwdArgs(Structure):
         ("dquery", c_void_p), ("dw_in", c_void_p), ("db_in", c_void_p), ("dw_out", c_void_p),
         ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
-        ("grad_dtype", c_int32), ("flags", c_int32), ("saved_prep", c_void_p), ("out_grads_event", c_void_p),
+        ("grad_dtype", c_int32), ("flags", c_int32), ("saved_prep", c_void_p), ("param_grads_event", c_void_p),
     ]
 
 

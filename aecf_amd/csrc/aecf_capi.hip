@@ -445,14 +445,6 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     t1.u_splits = 0; t1.u_rows_per_split = 0;
     launch_gemm_tn(d->dtype, t1, s);
     const int gb = a->grad_dtype == AECF_BF16 ? 1 : 0;
-    if (a->out_grads_event) {                  // dW_o / db_o final now: reduce their slabs and tell the caller
-        ReduceSegs re;
-        for (int i = 0; i < ReduceSegs::N; ++i) { re.src[i] = nullptr; re.dst[i] = nullptr; re.n[i] = 0; re.splits[i] = 0; re.dst_bf16[i] = gb; }
-        re.src[0] = (const float*)(ws + L.slab_o); re.dst[0] = a->dw_out; re.n[0] = (int64_t)E * E; re.splits[0] = L.splits;
-        re.src[1] = (const float*)(ws + L.cs_o);   re.dst[1] = a->db_out; re.n[1] = E;              re.splits[1] = L.splits;
-        launch_reduce_segments(re, s);
-        (void)hipEventRecord((hipEvent_t)a->out_grads_event, s);
-    }
     mark(ev, 3, s);
 
     BwdGArgs g2;
@@ -468,7 +460,10 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     else if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
         launch_bwd_g(d->dtype, g2, false, s);
     mark(ev, 4, s);
-    if (!(d->dtype == AECF_BF16 && launch_dx_ws(g2, s))) launch_bwd_g(d->dtype, g2, true, s);
+    // input gradient: here, or -- when the caller wants to be told the moment the parameter gradients are final -- last
+    const bool dx_last = a->param_grads_event != nullptr;
+    auto run_dx = [&]() { if (!(d->dtype == AECF_BF16 && launch_dx_ws(g2, s))) launch_bwd_g(d->dtype, g2, true, s); };
+    if (!dx_last) run_dx();
     mark(ev, 5, s);
 
     // dW_v = do^T pooled, db_v = colsum(do), u = ds^T x
@@ -497,7 +492,6 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = (char*)a->dw_in + (size_t)2 * E * E * gsz; rs.n[2] = (int64_t)E * E;
     rs.src[3] = (const float*)(ws + L.cs_v);   rs.dst[3] = (char*)a->db_in + (size_t)2 * E * gsz;  rs.n[3] = E;
     rs.src[4] = (const float*)(ws + L.u_slab); rs.dst[4] = u;                                      rs.n[4] = (int64_t)H * E;
-    if (a->out_grads_event) rs.n[0] = rs.n[1] = 0;                   // (already reduced and announced)
     launch_reduce_segments(rs, s);
 
     FinalizeArgs f;
@@ -505,6 +499,10 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     f.dq_part = (float*)(ws + L.dq_part); f.dw_in = a->dw_in;
     f.db_in = a->db_in; f.dquery = a->dquery; f.E = E; f.H = H; f.hd = hd; f.scale = scale; f.grad_bf16 = gb;
     launch_finalize(d->dtype, f, s);
+    if (dx_last) {
+        (void)hipEventRecord((hipEvent_t)a->param_grads_event, s);
+        run_dx();
+    }
     mark(ev, 8, s);
     return launch_status();
 }
@@ -694,7 +692,7 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
 
 int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream) {
     hipStream_t user = (hipStream_t)stream;
-    if (d && a && !a->stage_events && !a->out_grads_event && !(a->flags & AECF_PRECISE) && graphs_enabled(d)) {
+    if (d && a && !a->stage_events && !a->param_grads_event && !(a->flags & AECF_PRECISE) && graphs_enabled(d)) {
         const GraphKey key{1, 0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
                            (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->d_entropy ? 4 : 0) | (a->grad_dtype << 4)};
         int status = AECF_OK;

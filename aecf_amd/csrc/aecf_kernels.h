@@ -145,6 +145,8 @@ struct GemmTnArgs {
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b64_tr_b16 form (main product only)
+bool gemm_tn_pm_supported(const GemmTnArgs& a);                // pooled product with the pooling on the matrix pipe
+void launch_gemm_tn_pm(const GemmTnArgs& a, hipStream_t s);
 
 // dst[g][i] = sum_s src[g][s*n[g] + i] for each of N segments, one launch
 struct ReduceSegs {

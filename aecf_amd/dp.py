@@ -201,37 +201,37 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
 
 
 class GradOverlap:
-    """Starts the all-reduce of the fusion layer's out-projection gradients BEHIND the rest of its backward.
+    """Runs the all-reduce of the fusion layer's parameter gradients BEHIND the input-gradient kernel of its backward.
 
-    dW_o and db_o are final after the third of the backward's eight stages; the library announces that moment with a HIP
-    event (aecf_pool_bwd_args.out_grads_event) and this object -- installed as ``layer._out_grads_hook`` -- makes a side
-    stream wait for it and issues their collective there, in place on the tail of the gradient allocation.  ``finish``
-    reduces the rest (query and in-projection gradients) and makes the current stream wait for both.  Use:
+    With this object installed (as ``layer._param_grads_hook``) the backward computes dx last and the library announces
+    the moment the five parameter gradients are final with a HIP event (aecf_pool_bwd_args.param_grads_event); a side
+    stream waits for that event and issues ONE collective there, in place on the gradient allocation, while the dx
+    kernel runs on the caller's stream.  ``finish`` makes the current stream wait for it (and reduces, the plain way,
+    any parameters the layer's allocation does not cover).  Use:
 
         overlap = dp.GradOverlap()
         with overlap:                 # installs / removes the hook
             loss.backward()
             overlap.finish(params)    # instead of dp.all_reduce_grads(params)
 
-    The collective is a few hundred KB and latency-bound on xGMI; what this buys is that its latency runs concurrently
-    with the remaining backward kernels instead of after them."""
+    The collective is ~2 MB and latency-bound on xGMI; dx is ~13 % of the step, which is what it can hide behind."""
 
     def __init__(self, group=None, average: bool = True):
         self.group, self.average = group, average
         self.stream = None
-        self.tail = None
+        self.flat = None
         self.work = None
 
     def __enter__(self):
         from . import layer
         _, world = world_info(self.group)
         if world > 1:
-            layer._out_grads_hook = self
+            layer._param_grads_hook = self
         return self
 
     def __exit__(self, *exc):
         from . import layer
-        layer._out_grads_hook = None
+        layer._param_grads_hook = None
         return False
 
     def _reduce(self, flat, async_op):
@@ -242,33 +242,32 @@ class GradOverlap:
             flat.div_(world)
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
-    def __call__(self, tail: torch.Tensor, event) -> None:
+    def __call__(self, flat: torch.Tensor, event) -> None:
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=tail.device)
-        self.stream.wait_event(event)                       # the tail is final once the library's event has fired
+            self.stream = torch.cuda.Stream(device=flat.device)
+        self.stream.wait_event(event)                       # the gradients are final once the library's event has fired
         with torch.cuda.stream(self.stream):
-            self.work = self._reduce(tail, async_op=True)
-        self.tail = tail
+            self.work = self._reduce(flat, async_op=True)
+        flat.record_stream(self.stream)
+        self.flat = flat
 
     def finish(self, params: Iterable[torch.nn.Parameter]) -> None:
-        """All-reduce whatever the early collective did not cover, then make the current stream wait for both."""
+        """Wait for the collective issued behind dx; all-reduce whatever it did not cover."""
         params = [p for p in params if p.requires_grad and p.grad is not None]
         _, world = world_info(self.group)
         if world == 1 or not params:
             return
-        flat = flat_grad_alias(params)
-        if flat is None or self.tail is None or self.tail.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
-            if self.work is not None:                       # gradients did not come out as one allocation: plain path
-                self.work.wait()
-                torch.cuda.current_stream().wait_stream(self.stream)
-                self.tail = self.work = None
+        if self.work is None:                               # the hook never fired (no fused backward ran): plain path
             all_reduce_grads(params, self.group, self.average)
             return
-        head = flat[:flat.numel() - self.tail.numel()]
-        self._reduce(head, async_op=False)
         self.work.wait()
         torch.cuda.current_stream().wait_stream(self.stream)
-        self.tail = self.work = None
+        lo = self.flat.data_ptr()
+        hi = lo + self.flat.numel() * self.flat.element_size()
+        rest = [p for p in params if not (lo <= p.grad.data_ptr() < hi)]
+        self.flat = self.work = None
+        if rest:
+            all_reduce_grads(rest, self.group, self.average)
 
 
 class _AllGatherRows(torch.autograd.Function):

@@ -71,10 +71,10 @@ def _require_device(t: torch.Tensor, what: str) -> None:
 # compare against the backward's own preparation stage
 _SHARE_PREP = True
 
-# Data-parallel overlap hook (aecf_amd/dp.py: GradOverlap): when set, the backward asks the library to announce (a HIP
-# event) the moment dW_o / db_o are final and hands the hook that event together with the tail of the gradient allocation
-# that holds them, so that their all-reduce can start behind the rest of the backward.  None = off.
-_out_grads_hook = None
+# Data-parallel overlap hook (aecf_amd/dp.py: GradOverlap): when set, the backward asks the library to compute the input
+# gradient last and to announce (a HIP event) the moment the five parameter gradients are final, and hands the hook that
+# event together with the allocation that holds them, so that their all-reduce runs behind the dx kernel.  None = off.
+_param_grads_hook = None
 
 # what the library answers per call shape (status of aecf_pool_check, workspace sizes, whether the backward wants V):
 # pure functions of the description, asked once per shape instead of on every call (each ctypes round trip is ~1-2 us of a
@@ -199,7 +199,7 @@ class _PoolFunction(torch.autograd.Function):
         dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
         ws_bytes = ctx.bwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        hook, early = _out_grads_hook, None
+        hook, early = _param_grads_hook, None
         if hook is not None:
             early = torch.cuda.Event()
             early.record()                         # (creates the underlying hipEvent; the library records it again later)
@@ -211,7 +211,7 @@ class _PoolFunction(torch.autograd.Function):
             _DTYPES[gdt], 0, _ptr(saved_prep), None if early is None else early.cuda_event)
         _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")
         if hook is not None:
-            hook(flat[E + 3 * E * E + 3 * E:], early)      # [dw_out | db_out]: final once `early` has fired
+            hook(flat, early)                      # [dquery | dw_in | db_in | dw_out | db_out]: final once `early` has fired
         needs = ctx.needs_input_grad
         return (dx if needs[0] else None,
                 dquery.to(qd).reshape(ctx.q_shape) if needs[1] else None,

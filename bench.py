@@ -64,8 +64,8 @@ def make_inputs(cfg, device, seed_offset=0):
 
 def step(pool, query, x, dy, params, dp_on, uniforms=None, overlap=None):
     """One pass of the hot path over one resident batch: forward (+ entropy_loss) + backward (+ the gradient all-reduce
-    when data-parallel: the out-projection gradients' collective starts behind the rest of the backward, dp.GradOverlap;
-    --no-overlap: one collective after the backward)."""
+    when data-parallel: ONE collective, issued behind the backward's last kernel (dx) on a side stream, dp.GradOverlap;
+    --no-overlap: the same collective after the backward)."""
     B = x.shape[0]
     out, info = pool(query.expand(B, -1, -1), x, return_info=True, uniforms=uniforms)
     ent_loss = pool.curriculum_masking.entropy_loss(info["entropy"])
@@ -374,7 +374,7 @@ def main():
                        "parallelism": f"dp{world}", "world_size": world,
                        "collectives": None if world == 1 else (
                            f"{backend}: all-reduce of {4 * E * E + 5 * E} grads/step" +
-                           (" (out-projection part started behind the backward)" if overlap is not None else " (one call)"))},
+                           (" (one call, behind the dx kernel)" if overlap is not None else " (one call, after the backward)"))},
             "roofline": roofline,
             "path_hbm_frac": path_bytes * B / sec / 1e9 / HBM_PEAK_GBS,
             "path_mfma_frac": path_flops * B / sec / 1e12 / MFMA_PEAK_TFLOPS,

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AECF_ABI_VERSION 4
+#define AECF_ABI_VERSION 5
 
 typedef enum aecf_status {
     AECF_OK = 0,
@@ -156,11 +156,12 @@ typedef struct aecf_pool_bwd_args {
     int32_t grad_dtype;
     int32_t flags;               /* AECF_PRECISE: dy bf16; saved_o, dx and the gradients float32 (see aecf_pool_fwd_args.flags) */
     const void* saved_prep;      /* buffer filled by aecf_pool_forward (see aecf_pool_fwd_args.saved_prep) or NULL */
-    /* optional hipEvent_t (caller-created): recorded on `stream` as soon as dw_out and db_out are FINAL -- after the third
-     * backward stage, with the score gradient, dx and dW_v still to come -- so that a data-parallel caller can start
-     * their all-reduce on another stream behind the rest of the backward (aecf_amd/dp.py: GradOverlap).  Costs one
-     * extra small launch (their slab reduction leaves the final reduction).  NULL = off. */
-    void* out_grads_event;
+    /* optional hipEvent_t (caller-created): recorded on `stream` as soon as ALL FIVE parameter gradients (dquery, dw_in,
+     * db_in, dw_out, db_out) are final.  With it set the backward computes the input gradient dx LAST (otherwise it comes
+     * before dW_v), so a data-parallel caller can run the gradients' all-reduce on another stream behind the dx kernel
+     * (aecf_amd/dp.py: GradOverlap).  stage_events are not recorded in this order of stages; graph replay is off.
+     * NULL = off. */
+    void* param_grads_event;
 } aecf_pool_bwd_args;
 
 #define AECF_FWD_STAGES 4   /* prep, gate, vproj, outproj */
