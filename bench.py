@@ -41,7 +41,8 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16
-PROFILE_TAG = "r02"            # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
+PROFILE_TAG = "r02"              # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
+STAGE_PASS_STEPS = 30            # steps of the per-stage HIP-event pass (roofline), run before the warmup
 
 
 def make_inputs(cfg, device, seed_offset=0):
@@ -107,8 +108,7 @@ class StageTimer:
         lib = _lib.load()
         self.names = [("fwd." + lib.aecf_pool_stage_name(0, i).decode()) for i in range(self.nf)] + \
                      [("bwd." + lib.aecf_pool_stage_name(1, i).decode()) for i in range(self.nb)]
-        self.acc = [0.0] * (self.nf + self.nb)
-        self.n = 0
+        self.samples = [[] for _ in range(self.nf + self.nb)]
 
     def arm(self):
         self._lib.stage_events_fwd = self.fwd
@@ -124,12 +124,12 @@ class StageTimer:
         for arr in (self.fwd, self.bwd):
             for i in range(len(arr) - 1):
                 assert self.hip.hipEventElapsedTime(ctypes.byref(ms), arr[i], arr[i + 1]) == 0
-                self.acc[k] += ms.value
+                self.samples[k].append(ms.value)
                 k += 1
-        self.n += 1
 
-    def mean_ms(self):
-        return {n: a / max(self.n, 1) for n, a in zip(self.names, self.acc)}
+    def median_ms(self):
+        """Per-stage median over the pass (its first steps run while the device's clocks are still settling)."""
+        return {n: sorted(v)[len(v) // 2] if v else 0.0 for n, v in zip(self.names, self.samples)}
 
 
 def stage_model(cfg):
@@ -300,38 +300,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (same stream)
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        one_step()
-        marks[i + 1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    median_ms = per_step[len(per_step) // 2]
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
-
-    # per-stage durations (HIP events the library records on its launch stream), measured live over extra steps after
-    # the timed region
+    # per-stage durations (HIP events the library records on its launch stream), measured live over STAGE_PASS_STEPS extra
+    # steps BEFORE the warmup and the timed region, per-stage median.  (Side effect, stated in the line as "stage_pass": a
+    # fresh process needs ~15 steps / ~10 ms before its step time settles -- tools/step_trend.py: 0.83, 0.71, 0.68 ... 0.615 ms
+    # -- and with this pass first the W warmup steps no longer carry that.)
     roofline = None
     stages = None
     if rank == 0:
         st = StageTimer()
-        for _ in range(min(args.steps, 20)):
+        for _ in range(STAGE_PASS_STEPS):
             st.arm()
             step(pool, query, x, dy, params, False, None)
             st.disarm()
             torch.cuda.synchronize()
             st.collect()
-        stages = st.mean_ms()
+        stages = st.median_ms()
         model = stage_model(cfg)
         dom = max((k for k in stages if k in model), key=lambda k: stages[k])
         # HBM bytes per launch of that stage from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
@@ -353,6 +336,25 @@ def main():
         else:
             roofline = dict(bound="mfma", achieved=tfl, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=tfl / MFMA_PEAK_TFLOPS, traffic=traffic, kernel=dom, kernel_ms=stages[dom], **both)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (same stream)
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        one_step()
+        marks[i + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2]
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
 
     if rank == 0:
         sec = elapsed / args.steps
@@ -379,6 +381,7 @@ def main():
             "path_hbm_frac": path_bytes * B / sec / 1e9 / HBM_PEAK_GBS,
             "path_mfma_frac": path_flops * B / sec / 1e12 / MFMA_PEAK_TFLOPS,
             "stage_ms": stages,
+            "stage_pass": {"steps": STAGE_PASS_STEPS, "when": "before warmup", "stat": "median"},
             "cpu_baseline": cb,
         }
         print(json.dumps(line), flush=True)
