@@ -306,14 +306,14 @@ def main():
     # -- and with this pass first the W warmup steps no longer carry that.)
     roofline = None
     stages = None
+    st = StageTimer()                    # (every rank runs the pass -- the same start-up for all -- rank 0 reports it)
+    for _ in range(STAGE_PASS_STEPS):
+        st.arm()
+        step(pool, query, x, dy, params, False, None)
+        st.disarm()
+        torch.cuda.synchronize()
+        st.collect()
     if rank == 0:
-        st = StageTimer()
-        for _ in range(STAGE_PASS_STEPS):
-            st.arm()
-            step(pool, query, x, dy, params, False, None)
-            st.disarm()
-            torch.cuda.synchronize()
-            st.collect()
         stages = st.median_ms()
         model = stage_model(cfg)
         dom = max((k for k in stages if k in model), key=lambda k: stages[k])
