@@ -387,12 +387,13 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     constexpr int KX = (3 * H_ + 31) / 32;
     constexpr int RAW = 16 * ROWB;
     constexpr int HM = H_ * M_, NST = 16 * HM;
+    constexpr int HMS = HM | 1;                                    // stage row stride in floats: odd, so the 16 samples' reads of one (h, m) hit 16 banks
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int XROWB = 64 * KX;                                // bytes per row of the key-side operand tile
+    constexpr int XROWB = 64 * KX + 16;                           // bytes per row of the key-side operand tile (+16: the samples' rows start in different banks)
     constexpr int XT = 16 * M_ * XROWB;
     char* raw = smem;                                             // [2][16][K] do rows, chunk ^ row
     float* stage = reinterpret_cast<float*>(smem + 2 * RAW);      // [2][16][H][M] softmax weights, double buffered
-    char* xtra = smem + 2 * RAW + 2 * NST * 4;                    // [2][16*M][32*KX] bf16 [ds_hi | ds_lo | ds_hi] rows
+    char* xtra = smem + 2 * RAW + 2 * 16 * HMS * 4;               // [2][16*M][32*KX (+8)] bf16 [ds_hi | ds_lo | ds_hi] rows
 
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     const int E = p.E;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             const int idx = threadIdx.x + 512 * i;
             asm volatile("" : "+v"(stg[i][0]), "+v"(stg[i][1]));
             if (idx < NST) {
-                stage[buf * NST + idx] = stg[i][0];
+                stage[buf * 16 * HMS + (idx / HM) * HMS + idx % HM] = stg[i][0];
                 const int bb = idx / HM, rem = idx - bb * HM, h = rem / M_, m = rem - h * M_;
                 const float d = stg[i][1];
                 const unsigned short hi = X::from_f32(d);
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             load_stage(o0 + 16);
         }
         const char* tb = raw + cur * RAW;
-        const float* sp = stage + cur * NST + r16 * HM;            // this lane's sample: probs[h][m]
+        const float* sp = stage + cur * 16 * HMS + r16 * HMS;      // this lane's sample: probs[h][m]
         const char* xq = xtra + cur * XT + r16 * M_ * XROWB + 16 * lg;
         f32x4 acc[M_][CT];
 #pragma unroll
@@ -647,23 +648,34 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     // 2 ct to the chunk index BEFORE the xor with the sample, which (2 ct < 8, ncol0 / 8 a multiple of 8) is an xor of the
     // byte offset with 32 ct
     const int xaddr0 = r16 * M_ * ROWX + (((((ncol0 >> 3) + (lg >> 1))) ^ r16) << 4) + 8 * (lg & 1);
-    // transposed-read addresses of the u product (constant over the steps): K-step ks, rows 32 ks + 8 lg + q (+ 4),
-    // columns of tile 0; rows past the tile come from the zero page.  Relative to the x buffer / to smem for the zero page.
+    // transposed-read addresses of the u product (constant over the steps).  The K index of that product is any
+    // numbering of the tile's (sample, modality) rows, as long as the ds operand arrays use the same one -- and the
+    // row stride is a multiple of the 256-byte bank window, so rows read together must differ in their swizzle key
+    // (= sample) by more than its low bit.  K slot s = 32 ks + 8 lg + 4 hh + q: the 8 rows a 32-lane half of one
+    // transposed read touches (lg & 1, q) are the samples b = 2 j + parity, j = 4 (lg & 1) + q, of ONE modality m, with
+    // (m, parity) = the "domain" D = 4 ks + 2 hh + (lg >> 1) = 2 m + parity; domains >= 2 M read the zero page.
+    // (Rows in tile order -- 8 consecutive (b, m) rows per half -- shared keys three ways: SQ_LDS_BANK_CONFLICT was half
+    // of SQ_LDS_IDX_ACTIVE for this kernel.)
     const int q = r16 >> 2, pp = r16 & 3;
     int ua[KU][2];
-    bool uz[KU];
+    bool uz[KU][2];
 #pragma unroll
     for (int ks = 0; ks < KU; ++ks) {
-        const int row0 = 32 * ks + 8 * lg;
-        uz[ks] = row0 >= XROWS;                                   // (8-row groups never straddle the end: XROWS % 16 == 0)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const int row = row0 + 4 * hh + q;
-            const int key = uz[ks] ? 0 : (row / M_) & 15;
+            const int D = 4 * ks + 2 * hh + (lg >> 1);
+            uz[ks][hh] = D >= 2 * M_;
+            const int m = D >> 1, b = 2 * (4 * (lg & 1) + q) + (D & 1);
+            const int key = uz[ks][hh] ? 0 : b;
             const int ch = ((ncol0 >> 3) + (pp >> 1)) ^ key;
-            ua[ks][hh] = (uz[ks] ? (int)(zp - smem) + (row - XROWS) * ROWX : row * ROWX) + (ch << 4) + 8 * (pp & 1);
+            ua[ks][hh] = (uz[ks][hh] ? (int)(zp - smem) : (b * M_ + m) * ROWX) + (ch << 4) + 8 * (pp & 1);
         }
     }
+    // K slot of (sample b, modality m) in that numbering (the ds threads write their operand entries there)
+    auto kslot = [&](int b, int m) -> int {
+        const int D = 2 * m + (b & 1), j = b >> 1;
+        return 32 * (D >> 2) + 8 * (2 * (D & 1) + (j >> 2)) + 4 * ((D >> 1) & 1) + (j & 3);
+    };
 
     // ds threads: one wave per local head, lane = 16 m + sample (lane groups m >= M_ idle): the partial dots of a lane's
     // (sample, m) are contiguous over the lanes (conflict-free LDS reads), the sum over m is a lane-group reduction
@@ -706,7 +718,6 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
             load_stats(o0 + 16, pmv_n, dwb_n);
         }
         const char* tb = db + cur * DT;
-        const char* tx = xb + cur * XT;
         // heads in groups of HG: P_h by MFMA, then the dot with this lane's x values (8-byte LDS reads at a per-tile base +
         // an immediate; one read and one unpack serve the HG heads of the group).  Every lane writes its partial (16 NCT
         // columns of one sample) to part[wave, lane group][head, m][sample]; the ds threads add the 32 of them.
@@ -797,8 +808,8 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 const float d = (b < o_end) ? pmv * (dp - dot) : 0.f;
                 if (b < o_end) p.dsbuf[(b * H + hbase + ds_hh) * M_ + ds_m] = d;
                 const unsigned short hi = X::from_f32(d);
-                dsh[ds_hh * 64 + ds_s * M_ + ds_m] = hi;
-                dsl[ds_hh * 64 + ds_s * M_ + ds_m] = X::from_f32(d - X::to_f32(hi));
+                dsh[ds_hh * 64 + kslot(ds_s, ds_m)] = hi;
+                dsl[ds_hh * 64 + kslot(ds_s, ds_m)] = X::from_f32(d - X::to_f32(hi));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -808,10 +819,10 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
         for (int ks = 0; ks < KU; ++ks) {
             const u32x4 bh = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dsh) + (r16 * 64 + 32 * ks + 8 * lg) * 2);
             const u32x4 bl = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dsl) + (r16 * 64 + 32 * ks + 8 * lg) * 2);
-            const char* base = uz[ks] ? smem : tx;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                const u32x4 af = tr_frag16(base, ua[ks][0] ^ (32 * ct), ua[ks][1] ^ (32 * ct));
+                const u32x4 af = tr_frag16(smem, (uz[ks][0] ? 0 : cur * XT) + (ua[ks][0] ^ (32 * ct)),
+                                           (uz[ks][1] ? 0 : cur * XT) + (ua[ks][1] ^ (32 * ct)));
                 uacc[ct] = X::mma(af, bh, uacc[ct]);
                 uacc[ct] = X::mma(af, bl, uacc[ct]);
             }
@@ -859,7 +870,7 @@ void launch_dx2(const BwdGArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
     constexpr int CT = KT <= 16 ? 2 : 1;
     constexpr int KX = (3 * (KT / HK) + 31) / 32;
-    const size_t smem = (size_t)2 * 16 * 2 * K + (size_t)2 * 16 * (KT / HK) * M_ * sizeof(float) + (size_t)2 * 16 * M_ * 64 * KX;
+    const size_t smem = (size_t)2 * 16 * 2 * K + (size_t)2 * 16 * (((KT / HK) * M_) | 1) * sizeof(float) + (size_t)2 * 16 * M_ * (64 * KX + 16);
     const int groups = a.E / (128 * CT);
     int64_t chunks = 256 / groups;
     if (chunks < 1) chunks = 1;
