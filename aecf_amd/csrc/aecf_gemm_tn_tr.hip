@@ -631,12 +631,14 @@ void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s) {
     if (use_pm && gemm_tn_pm_supported(a)) { launch_gemm_tn_pm(a, s); return; }
     // 256-row tiles (1024 threads) when they tile E exactly with at most 4 head slots and M <= 3 (128-VGPR budget)
     static const int no_wide = getenv("AECF_NO_WIDE_TN") ? atoi(getenv("AECF_NO_WIDE_TN")) : 0;      // A/B timing only
-    if (!no_wide && a.Ej <= 0 && a.E % 256 == 0 && a.M <= 3 && max_slots_256(a.E, a.hd) <= 4) {
+    if (!no_wide && a.Ej <= 0 && a.E % 256 == 0 && max_slots_256(a.E, a.hd) <= 4 &&
+        (a.M <= 3 || (a.M == 4 && max_slots_256(a.E, a.hd) <= 2))) {
         const bool two = max_slots_256(a.E, a.hd) <= 2;
         switch (a.M) {
             case 1: if (two) launch_wide<1, 2>(a, s); else launch_wide<1, 4>(a, s); return;
             case 2: if (two) launch_wide<2, 2>(a, s); else launch_wide<2, 4>(a, s); return;
-            default: if (two) launch_wide<3, 2>(a, s); else launch_wide<3, 4>(a, s); return;
+            case 3: if (two) launch_wide<3, 2>(a, s); else launch_wide<3, 4>(a, s); return;
+            default: launch_wide<4, 2>(a, s); return;
         }
     }
     const int ns = max_slots_128(a.E, a.hd);
