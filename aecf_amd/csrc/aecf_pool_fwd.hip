@@ -189,14 +189,17 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
 // ------------------------------------------------------------------------------------------
 // gate_fwd: scores via MFMA (x rows as the A operand, A^T as the B operand), softmax over the M
 // modalities in registers, head mean by a 16-lane butterfly, curriculum masking per sample.
-// One wave = 16 samples; a block = 4 waves.
-template <typename T, int M_>
+// One wave = 16 samples; a block = 4 waves.  KSPLIT (small batches: fewer than ~8 waves per CU would otherwise be all
+// the memory-level parallelism there is): the block's 4 waves take a quarter of K each for the SAME 16 samples, the
+// partial scores are added through LDS in wave order and wave 0 finishes the samples.
+template <typename T, int M_, bool KSPLIT>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(GateArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
     typedef typename X::frag frag;
+    __shared__ float kpart[KSPLIT ? 3 * M_ * 4 * 64 : 1];
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
-    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave_id()) * 16;
+    const int64_t b0 = KSPLIT ? (int64_t)blockIdx.x * 16 : ((int64_t)blockIdx.x * 4 + wave_id()) * 16;
     if (b0 >= p.B) return;
     const int E = p.E, H = p.H;
     const int64_t brow = (b0 + r16 < p.B) ? (b0 + r16) : (p.B - 1);
@@ -208,18 +211,56 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(GateArgs p) {
 #pragma unroll
     for (int m = 0; m < M_; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < E; k0 += X::KSTEP) {
-        frag bh = X::load(ahi + k0);
-        frag bl;
-        if (X::BYTES == 2) bl = X::load(alo + k0);
+    // The score of a (sample, head, modality) is DEFINED as the sum, in order, of its four K-quarter products whenever K
+    // splits into quarters of whole K-steps -- so that the KSPLIT form (one quarter per wave) and this one give the same
+    // bits, and a sample's result does not depend on the batch it arrives in.
+    const bool quarters = E % (4 * X::KSTEP) == 0;
+    auto span = [&](int kbeg, int kend, f32x4* a) {
+        for (int k0 = kbeg; k0 < kend; k0 += X::KSTEP) {
+            frag bh = X::load(ahi + k0);
+            frag bl;
+            if (X::BYTES == 2) bl = X::load(alo + k0);
 #pragma unroll
-        for (int m = 0; m < M_; ++m) {
-            frag xf = X::load(xrow + (int64_t)m * E + k0);
-            acc[m] = X::mma(xf, bh, acc[m]);
-            if (X::BYTES == 2) acc[m] = X::mma(xf, bl, acc[m]);
+            for (int m = 0; m < M_; ++m) {
+                frag xf = X::load(xrow + (int64_t)m * E + k0);
+                a[m] = X::mma(xf, bh, a[m]);
+                if (X::BYTES == 2) a[m] = X::mma(xf, bl, a[m]);
+            }
         }
+    };
+    if (KSPLIT) {
+        span(wave_id() * (E / 4), (wave_id() + 1) * (E / 4), acc);
+    } else if (quarters) {
+        span(0, E / 4, acc);
+        for (int qk = 1; qk < 4; ++qk) {
+            f32x4 part[M_];
+#pragma unroll
+            for (int m = 0; m < M_; ++m) part[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            span(qk * (E / 4), (qk + 1) * (E / 4), part);
+#pragma unroll
+            for (int m = 0; m < M_; ++m) acc[m] += part[m];
+        }
+    } else {
+        span(0, E, acc);
     }
 
+    if (KSPLIT) {                                  // waves 1..3 hand their partial scores to wave 0 (fixed order of addition)
+        const int w = wave_id();
+        if (w > 0) {
+#pragma unroll
+            for (int m = 0; m < M_; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kpart[(((w - 1) * M_ + m) * 4 + r) * 64 + lane] = acc[m][r];
+        }
+        __syncthreads();
+        if (w > 0) return;
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+            for (int m = 0; m < M_; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][r] += kpart[((ww * M_ + m) * 4 + r) * 64 + lane];
+    }
     // acc[m][r]: sample b0 + 4*lg + r, head r16
     float pr[M_][4];
 #pragma unroll
@@ -397,12 +438,18 @@ void launch_gate_stats(int dtype, const GateArgs& a, hipStream_t s) {
 }
 
 void launch_gate_fwd(int dtype, const GateArgs& a, hipStream_t s) {
-    dim3 grid((unsigned)((a.B + 63) / 64)), block(256);
+    // fewer than ~2048 waves of 16 samples (8 per CU): split K over the block's waves instead of the samples
+    const int kstep = dtype == 0 ? 32 : 16;
+    const bool ksplit = (a.B + 15) / 16 < 2048 && a.E % (4 * kstep) == 0;
+    dim3 grid((unsigned)(ksplit ? (a.B + 15) / 16 : (a.B + 63) / 64)), block(256);
     AECF_DISPATCH_M(a.M, {
-        if (dtype == 0)
-            gate_fwd_kernel<BF16, M_><<<grid, block, 0, s>>>(a);
-        else
-            gate_fwd_kernel<F32, M_><<<grid, block, 0, s>>>(a);
+        if (dtype == 0) {
+            if (ksplit) gate_fwd_kernel<BF16, M_, true><<<grid, block, 0, s>>>(a);
+            else gate_fwd_kernel<BF16, M_, false><<<grid, block, 0, s>>>(a);
+        } else {
+            if (ksplit) gate_fwd_kernel<F32, M_, true><<<grid, block, 0, s>>>(a);
+            else gate_fwd_kernel<F32, M_, false><<<grid, block, 0, s>>>(a);
+        }
     });
 }
 
