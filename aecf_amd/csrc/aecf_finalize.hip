@@ -6,6 +6,7 @@
 //   dW_q     = dq' (x) q ;  dW_k[j,:] = qs[j] * u[h(j)] ;  db_q = dq' ;  db_k = 0    fin_outer (+ dquery partials)
 //   dquery   = W_q^T dq'                                                             fin_dquery
 // db_k is exactly zero: dK = ds (x) qs and every softmax-backward row of ds sums to zero.
+#include <stdlib.h>
 #include "aecf_kernels.h"
 
 namespace aecf {
@@ -60,13 +61,14 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs r) {
 // dq'[j] = scale * W_k[j,:] . u[h(j)]  for the 16 rows j of this block (wave per 4 rows), then
 // dW_q[j][k] = dq'[j] q[k], dW_k[j][k] = qs[j] u[h(j)][k], db_q = dq', db_k = 0 and the dquery partial
 // sum_j dq'[j] W_q[j][k] of these 16 rows.  grid (E/64 k-blocks, E/16 j-blocks); 256 threads = 64 k x 4 j-groups.
+// kc: 64-column slices per block (the dq' dot of a row block is repeated by every block of its row: wide embeddings
+// take several slices per block so that the repetition stays at E / (64 kc))
 template <typename T>
-__global__ __launch_bounds__(256) void fin_outer_kernel(FinalizeArgs p) {
+__global__ __launch_bounds__(256) void fin_outer_kernel(FinalizeArgs p, int kc) {
     using X = Tr<T>;
     __shared__ float red[4][64];
     __shared__ float dql[16];
     const int E = p.E;
-    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
     const int jg = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int jb = blockIdx.y;
     const typename X::elem* wq = reinterpret_cast<const typename X::elem*>(p.w_in);
@@ -92,22 +94,26 @@ __global__ __launch_bounds__(256) void fin_outer_kernel(FinalizeArgs p) {
         if (part == 0) dql[jj] = a * p.scale;
     }
     __syncthreads();
-    const float qk = X::to_f32(reinterpret_cast<const typename X::elem*>(p.query)[k]);
-    float part = 0.f;
-    for (int jj = jg; jj < 16; jj += 4) {
-        const int j = jb * 16 + jj;
-        const float dq = dql[jj];
-        store_grad(p.dw_in, (int64_t)j * E + k, dq * qk, p.grad_bf16);                                         // dW_q
-        store_grad(p.dw_in, (int64_t)(E + j) * E + k, p.qs[j] * p.u[(int64_t)(j / p.hd) * E + k], p.grad_bf16);   // dW_k
-        part = fmaf(dq, X::to_f32(wq[(int64_t)j * E + k]), part);
-        if (blockIdx.x == 0 && lane == 0) {
-            store_grad(p.db_in, j, dq, p.grad_bf16);         // db_q
-            store_grad(p.db_in, E + j, 0.f, p.grad_bf16);    // db_k
+    for (int c = 0; c < kc; ++c) {
+        const int k = (blockIdx.x * kc + c) * 64 + lane;
+        const float qk = X::to_f32(reinterpret_cast<const typename X::elem*>(p.query)[k]);
+        float part = 0.f;
+        for (int jj = jg; jj < 16; jj += 4) {
+            const int j = jb * 16 + jj;
+            const float dq = dql[jj];
+            store_grad(p.dw_in, (int64_t)j * E + k, dq * qk, p.grad_bf16);                                         // dW_q
+            store_grad(p.dw_in, (int64_t)(E + j) * E + k, p.qs[j] * p.u[(int64_t)(j / p.hd) * E + k], p.grad_bf16);   // dW_k
+            part = fmaf(dq, X::to_f32(wq[(int64_t)j * E + k]), part);
+            if (blockIdx.x == 0 && c == 0 && lane == 0) {
+                store_grad(p.db_in, j, dq, p.grad_bf16);         // db_q
+                store_grad(p.db_in, E + j, 0.f, p.grad_bf16);    // db_k
+            }
         }
+        if (c > 0) __syncthreads();
+        red[jg][lane] = part;
+        __syncthreads();
+        if (jg == 0) p.dq_part[(int64_t)jb * E + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
     }
-    red[jg][lane] = part;
-    __syncthreads();
-    if (jg == 0) p.dq_part[(int64_t)jb * E + k] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 __global__ __launch_bounds__(64) void fin_dquery_kernel(FinalizeArgs p) {
@@ -127,10 +133,13 @@ void launch_reduce_segments(const ReduceSegs& r, hipStream_t s) {
 
 void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s) {
     const int E = a.E;
+    static const int kc_env = getenv("AECF_FIN_KC") ? atoi(getenv("AECF_FIN_KC")) : 0;      // A/B timing only
+    int kc = kc_env > 0 ? kc_env : (E >= 1024 ? 4 : 1);           // keep >= 256 blocks
+    while ((E / 64) % kc != 0) --kc;
     if (dtype == 0) {
-        fin_outer_kernel<BF16><<<dim3(E / 64, E / 16), dim3(256), 0, s>>>(a);
+        fin_outer_kernel<BF16><<<dim3(E / 64 / kc, E / 16), dim3(256), 0, s>>>(a, kc);
     } else {
-        fin_outer_kernel<F32><<<dim3(E / 64, E / 16), dim3(256), 0, s>>>(a);
+        fin_outer_kernel<F32><<<dim3(E / 64 / kc, E / 16), dim3(256), 0, s>>>(a, kc);
     }
     fin_dquery_kernel<<<dim3((E + 63) / 64), dim3(64), 0, s>>>(a);
 }
