@@ -17,6 +17,7 @@ using namespace aecf;
 namespace {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+int env_dx_reserve();          // AECF_DX_RESERVE_CUS (same place)
 bool env_no_ws();              // AECF_NO_WS / AECF_NO_GATE_FUSION / AECF_FUSED_FWD, read once per process (defined with the graph cache)
 bool env_no_gate_fusion();
 bool env_fused_fwd();
@@ -462,6 +463,10 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     mark(ev, 4, s);
     // input gradient: here, or -- when the caller wants to be told the moment the parameter gradients are final -- last
     const bool dx_last = a->param_grads_event != nullptr;
+    // ... and then with a few CUs left free: the dx kernel otherwise takes every CU's whole register file for its one
+    // block, and the collective's workgroups could only start as those retire (AECF_DX_RESERVE_CUS, default 16 of 256;
+    // UNMEASURED here -- no multi-GPU box -- it costs the dx kernel ~6 % and is meant to buy the all-reduce its overlap)
+    if (dx_last) g2.cu_budget = 256 - env_dx_reserve();
     auto run_dx = [&]() { if (!(d->dtype == AECF_BF16 && launch_dx_ws(g2, s))) launch_bwd_g(d->dtype, g2, true, s); };
     if (!dx_last) run_dx();
     mark(ev, 5, s);
@@ -556,6 +561,7 @@ struct EnvSwitches {
     int graph;          // AECF_GRAPH: -1 unset, 0 off, 1 on
     bool no_ws;         // AECF_NO_WS: tiled kernels instead of the weight-stationary ones
     int no_gate_fusion; // AECF_NO_GATE_FUSION
+    int dx_reserve;     // AECF_DX_RESERVE_CUS: CUs the dx kernel leaves free when it runs beside a collective (default 16)
     int fused_fwd;      // AECF_FUSED_FWD=1: the one-kernel row-stationary forward (aecf_row_fwd.hip) instead of the
                         // weight-stationary pair (measured slower at C2: DESIGN.md section 5)
 };
@@ -566,6 +572,8 @@ const EnvSwitches& env_switches() {
         v.no_ws = getenv("AECF_NO_WS") != nullptr;
         v.no_gate_fusion = getenv("AECF_NO_GATE_FUSION") ? atoi(getenv("AECF_NO_GATE_FUSION")) : 0;
         v.fused_fwd = getenv("AECF_FUSED_FWD") ? atoi(getenv("AECF_FUSED_FWD")) : 0;
+        v.dx_reserve = getenv("AECF_DX_RESERVE_CUS") ? atoi(getenv("AECF_DX_RESERVE_CUS")) : 16;
+        if (v.dx_reserve < 0 || v.dx_reserve > 128) v.dx_reserve = 16;
         return v;
     }();
     return e;
@@ -574,6 +582,7 @@ const EnvSwitches& env_switches() {
 bool env_no_ws() { return env_switches().no_ws; }
 bool env_no_gate_fusion() { return env_switches().no_gate_fusion != 0; }
 bool env_fused_fwd() { return env_switches().fused_fwd != 0; }
+int env_dx_reserve() { return env_switches().dx_reserve; }
 
 // Measured (C2, same box, 3 x A/B): the graph form halves the HOST cost of a step (0.39 -> 0.20 ms) but the GPU runs the
 // large kernels ~2 % slower under it (0.632 vs 0.619 ms), so it is used where the host is the bound: calls whose

@@ -872,7 +872,7 @@ void launch_dx2(const BwdGArgs& a, hipStream_t s) {
     constexpr int KX = (3 * (KT / HK) + 31) / 32;
     const size_t smem = (size_t)2 * 16 * 2 * K + (size_t)2 * 16 * (((KT / HK) * M_) | 1) * sizeof(float) + (size_t)2 * 16 * M_ * (64 * KX + 16);
     const int groups = a.E / (128 * CT);
-    int64_t chunks = 256 / groups;
+    int64_t chunks = (a.cu_budget > 0 ? a.cu_budget : 256) / groups;
     if (chunks < 1) chunks = 1;
     int64_t rpb = (a.B + chunks - 1) / chunks;
     rpb = (rpb + 15) / 16 * 16;

@@ -109,6 +109,7 @@ struct BwdGArgs {
     int M, E, H, hd;
     float log_M;
     const void* wvt_frag = nullptr;  // optional fragment-major copy of W_v^T (FragJobs): faster dx weight prologue
+    int cu_budget = 0;               // dx_ws2: blocks to launch at most (0 = one per CU, 256); fewer leaves CUs to a collective
 };
 void launch_bwd_g(int dtype, const BwdGArgs& a, bool dx, hipStream_t s);
 // score gradient from the saved value projections: da[b,h,m] = do_h[b] . V_h[b,m]  (memory-bound, one wave per sample)
