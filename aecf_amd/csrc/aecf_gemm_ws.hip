@@ -597,7 +597,10 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     constexpr int ROWX = 2 * E, ROWD = 2 * JB;
     constexpr int XROWS = 16 * M_;                                // x tile rows (b, m)
     constexpr int KU = (XROWS + 31) / 32;                         // MFMA K-steps of the u product (K = x tile row)
-    constexpr int ZROWS = 32 * KU - XROWS;                        // K padding: rows of a shared all-zero page
+    constexpr int ZROWS = (32 * KU - XROWS) > 0 ? 1 : 0;          // K padding: one all-zero row (every padding slot reads it)
+    constexpr int PSTR = HBL * M_ * 16 + 16;                      // floats per partial block: + 16 so that the two lane groups of a
+                                                                  // 32-lane store half land in different banks
+    constexpr int DSROW = 72;                                     // ds operand row (64 K slots + 8): rows start 9 x 16 B apart
     constexpr int XT = XROWS * ROWX, DT = 16 * ROWD;
     constexpr int HM = HBL * M_;
     constexpr int NPART = 32;                                     // partial dots per (sample, head, m): 8 waves x 4 lane groups
@@ -606,8 +609,8 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     char* zp = smem + 2 * XT;                                     // [ZROWS][E] zeros
     char* db = zp + ZROWS * ROWX;                                 // [2][16][JB] do rows, chunk ^ row
     float* part = reinterpret_cast<float*>(db + 2 * DT);          // [32][HM][16 samples]
-    unsigned short* dsh = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(part) + NPART * 16 * HM * 4);   // [16][64] bf16 hi
-    unsigned short* dsl = dsh + 16 * 64;                                                                            // [16][64] bf16 lo
+    unsigned short* dsh = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(part) + NPART * PSTR * 4);     // [16][DSROW] bf16 hi
+    unsigned short* dsl = dsh + 16 * DSROW;                                                                          // [16][DSROW] bf16 lo
 
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(wave_id());
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     };
     // what the DMA never writes and the MFMAs still read: the zero page, the ds operand arrays
     for (int i = threadIdx.x; i < ZROWS * ROWX / 16; i += 512) reinterpret_cast<u32x4*>(zp)[i] = u32x4{0u, 0u, 0u, 0u};
-    for (int i = threadIdx.x; i < 2 * 16 * 64 / 2; i += 512) reinterpret_cast<unsigned int*>(dsh)[i] = 0u;
+    for (int i = threadIdx.x; i < 2 * 16 * DSROW / 2; i += 512) reinterpret_cast<unsigned int*>(dsh)[i] = 0u;
     issue(o_beg, 0);
 
     // ---- resident weights: A operand row r16 of column tile ct <-> k = ncol0 + 16 ct + r16, K = j
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
         int xa[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) xa[ct] = cur * XT + (xaddr0 ^ (32 * ct));
-        float* pw = part + (w * 4 + lg) * (HM * 16) + r16;
+        float* pw = part + (w * 4 + lg) * PSTR + r16;
 #pragma unroll
         for (int h0 = 0; h0 < HBL; h0 += HG) {
             f32x4 P[HG][NCT];
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
             if (ds_m < M_) {
                 const float* pr = part + (ds_hh * M_ + ds_m) * 16 + ds_s;
 #pragma unroll
-                for (int i = 0; i < NPART; ++i) da += pr[i * (HM * 16)];                 // fixed order
+                for (int i = 0; i < NPART; ++i) da += pr[i * PSTR];                      // fixed order
             }
             float dw = p.d_attn_w ? dwb : 0.f;
             if (p.d_entropy && ds_m < M_) {                        // eval mode: the entropy keeps its graph (ref :150-156)
@@ -808,8 +811,8 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 const float d = (b < o_end) ? pmv * (dp - dot) : 0.f;
                 if (b < o_end) p.dsbuf[(b * H + hbase + ds_hh) * M_ + ds_m] = d;
                 const unsigned short hi = X::from_f32(d);
-                dsh[ds_hh * 64 + kslot(ds_s, ds_m)] = hi;
-                dsl[ds_hh * 64 + kslot(ds_s, ds_m)] = X::from_f32(d - X::to_f32(hi));
+                dsh[ds_hh * DSROW + kslot(ds_s, ds_m)] = hi;
+                dsl[ds_hh * DSROW + kslot(ds_s, ds_m)] = X::from_f32(d - X::to_f32(hi));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -817,8 +820,8 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
         // u^T[k, h] += x^T[k, (b,m)] ds[(b,m), h]:  A operand by transposed reads of the x tile (rows = K index)
 #pragma unroll
         for (int ks = 0; ks < KU; ++ks) {
-            const u32x4 bh = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dsh) + (r16 * 64 + 32 * ks + 8 * lg) * 2);
-            const u32x4 bl = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dsl) + (r16 * 64 + 32 * ks + 8 * lg) * 2);
+            const u32x4 bh = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dsh) + (r16 * DSROW + 32 * ks + 8 * lg) * 2);
+            const u32x4 bl = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dsl) + (r16 * DSROW + 32 * ks + 8 * lg) * 2);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const u32x4 af = tr_frag16(smem, (uz[ks][0] ? 0 : cur * XT) + (ua[ks][0] ^ (32 * ct)),
@@ -842,9 +845,9 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
 template <int KT, int KJ, int HK, int M_>
 int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     constexpr int E = 32 * KT, JB = 32 * KJ, HBL = KJ / HK;
-    constexpr int XROWS = 16 * M_, ZROWS = 32 * ((XROWS + 31) / 32) - XROWS;
-    const size_t smem = (size_t)(2 * XROWS + ZROWS) * 2 * E + (size_t)2 * 16 * 2 * JB + (size_t)32 * 16 * HBL * M_ * 4 +
-                        (size_t)2 * 16 * 64 * 2;
+    constexpr int XROWS = 16 * M_, ZROWS = (32 * ((XROWS + 31) / 32) - XROWS) > 0 ? 1 : 0;
+    const size_t smem = (size_t)(2 * XROWS + ZROWS) * 2 * E + (size_t)2 * 16 * 2 * JB + (size_t)32 * (16 * HBL * M_ + 16) * 4 +
+                        (size_t)2 * 16 * 72 * 2;
     const int groups = E / JB;
     int64_t chunks = 256 / groups;
     if (chunks < 1) chunks = 1;
@@ -997,8 +1000,8 @@ int dsu_ws_chunks(const BwdGArgs& a) {
     const int hk = a.hd / 32;
     if (hk != 1 && hk != 2 && hk != 4 && hk != 8) return 0;
     {   // LDS: two x tiles + K-padding page + two do tiles + partial dots + ds operand arrays
-        const int xrows = 16 * a.M, zrows = 32 * ((xrows + 31) / 32) - xrows, hbl = jb / a.hd;
-        const size_t smem = (size_t)(2 * xrows + zrows) * 2 * a.E + (size_t)2 * 16 * 2 * jb + (size_t)32 * 16 * hbl * a.M * 4 + 4096;
+        const int xrows = 16 * a.M, zrows = (32 * ((xrows + 31) / 32) - xrows) > 0 ? 1 : 0, hbl = jb / a.hd;
+        const size_t smem = (size_t)(2 * xrows + zrows) * 2 * a.E + (size_t)2 * 16 * 2 * jb + (size_t)32 * (16 * hbl * a.M + 16) * 4 + 4608;
         if (smem > 160 * 1024) return 0;
     }
     const int groups = a.E / jb;
