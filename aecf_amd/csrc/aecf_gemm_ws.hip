@@ -598,12 +598,12 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     constexpr int XROWS = 16 * M_;                                // x tile rows (b, m)
     constexpr int KU = (XROWS + 31) / 32;                         // MFMA K-steps of the u product (K = x tile row)
     constexpr int ZROWS = (32 * KU - XROWS) > 0 ? 1 : 0;          // K padding: one all-zero row (every padding slot reads it)
-    constexpr int PSTR = HBL * M_ * 16 + 16;                      // floats per partial block: + 16 so that the two lane groups of a
-                                                                  // 32-lane store half land in different banks
+    constexpr int PSTR = HBL * M_ * 16;                           // floats per partial block (one per wave)
     constexpr int DSROW = 72;                                     // ds operand row (64 K slots + 8): rows start 9 x 16 B apart
     constexpr int XT = XROWS * ROWX, DT = 16 * ROWD;
     constexpr int HM = HBL * M_;
-    constexpr int NPART = 32;                                     // partial dots per (sample, head, m): 8 waves x 4 lane groups
+    constexpr int NPART = 8;                                      // partial dots per (sample, head, m): one per wave (its four
+                                                                  // lane groups are added in registers: v_permlane16/32_swap)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xb = smem;                                              // [2][16 M][E] x rows (b, m), 16-byte chunk ^ sample
     char* zp = smem + 2 * XT;                                     // [ZROWS][E] zeros
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
         int xa[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) xa[ct] = cur * XT + (xaddr0 ^ (32 * ct));
-        float* pw = part + (w * 4 + lg) * PSTR + r16;
+        float* pw = part + w * PSTR + r16;
 #pragma unroll
         for (int h0 = 0; h0 < HBL; h0 += HG) {
             f32x4 P[HG][NCT];
@@ -781,7 +781,16 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < HG; ++g) pw[((h0 + g) * M_ + m) * 16] = a[g];
+                for (int g = 0; g < HG; ++g) {
+                    // sum over the wave's four lane groups (lanes r16, r16 + 16, + 32, + 48): rows swapped pairwise, then halves
+                    const unsigned int ua = __float_as_uint(a[g]);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(ua, ua, false, false);
+                    const float s1 = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);
+                    const unsigned int us = __float_as_uint(s1);
+                    const auto r2 = __builtin_amdgcn_permlane32_swap(us, us, false, false);
+                    const float s2 = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+                    if (lg == 0) pw[((h0 + g) * M_ + m) * 16] = s2;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -846,7 +855,7 @@ template <int KT, int KJ, int HK, int M_>
 int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     constexpr int E = 32 * KT, JB = 32 * KJ, HBL = KJ / HK;
     constexpr int XROWS = 16 * M_, ZROWS = (32 * ((XROWS + 31) / 32) - XROWS) > 0 ? 1 : 0;
-    const size_t smem = (size_t)(2 * XROWS + ZROWS) * 2 * E + (size_t)2 * 16 * 2 * JB + (size_t)32 * (16 * HBL * M_ + 16) * 4 +
+    const size_t smem = (size_t)(2 * XROWS + ZROWS) * 2 * E + (size_t)2 * 16 * 2 * JB + (size_t)8 * (16 * HBL * M_) * 4 +
                         (size_t)2 * 16 * 72 * 2;
     const int groups = E / JB;
     int64_t chunks = 256 / groups;
@@ -1001,7 +1010,7 @@ int dsu_ws_chunks(const BwdGArgs& a) {
     if (hk != 1 && hk != 2 && hk != 4 && hk != 8) return 0;
     {   // LDS: two x tiles + K-padding page + two do tiles + partial dots + ds operand arrays
         const int xrows = 16 * a.M, zrows = (32 * ((xrows + 31) / 32) - xrows) > 0 ? 1 : 0, hbl = jb / a.hd;
-        const size_t smem = (size_t)(2 * xrows + zrows) * 2 * a.E + (size_t)2 * 16 * 2 * jb + (size_t)32 * (16 * hbl * a.M + 16) * 4 + 4608;
+        const size_t smem = (size_t)(2 * xrows + zrows) * 2 * a.E + (size_t)2 * 16 * 2 * jb + (size_t)8 * (16 * hbl * a.M) * 4 + 4608;
         if (smem > 160 * 1024) return 0;
     }
     const int groups = a.E / jb;
