@@ -207,7 +207,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     int cur = 0;
     for (int64_t o0 = o_beg; o0 < o_end; o0 += OROWS, cur ^= 1) {
         __builtin_amdgcn_s_barrier();                              // tile visible to all waves; other buffer free
-        if (o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);
+        // GATE: the next tile's copy is issued among the first MFMAs of the step (below), not here: at the top its six
+        // wave-instructions and their address arithmetic sit in front of the score phase, which every wave of the block
+        // then waits for at the second barrier (value projection 130 -> 121 us at C2)
+        if (!GATE && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);
         if (o0 + OROWS < o_end) load_probs(o0 + OROWS, pm_next);
 
         if (GATE) {
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
+            if (GATE && i == NIT / 8 && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);   // 7/8 of the MFMA phase to land in
             const int ks = PL ? i / RT : i % KT;
             const int t = PL ? i % RT : 0;
 #pragma unroll
