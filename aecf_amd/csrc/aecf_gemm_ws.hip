@@ -490,10 +490,7 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // do rows + stage of this step visible
-        if (o0 + 16 < o_end) {
-            issue(o0 + 16, cur ^ 1);
-            load_stage(o0 + 16);
-        }
+        if (o0 + 16 < o_end) load_stage(o0 + 16);                  // (the rows' copy is issued behind the first head's MFMAs, below)
         const char* tb = raw + cur * RAW;
         const float* sp = stage + cur * 16 * HMS + r16 * HMS;      // this lane's sample: probs[h][m]
         const char* xq = xtra + cur * XT + r16 * M_ * XROWB + 16 * lg;
@@ -536,6 +533,7 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             }
         };
         head_mma(0, Pc);
+        if (o0 + 16 < o_end) issue(o0 + 16, cur ^ 1);
 #pragma unroll
         for (int h = 0; h < H_; ++h) {
             if (h + 1 < H_) head_mma(h + 1, Pn);
