@@ -922,6 +922,241 @@ bool launch_dx2_hk(const BwdGArgs& a, hipStream_t s) {
     return false;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gated value projection, K = 512, with the tile stored as PER-WAVE COLUMN SLABS (the hot shape's form).
+// In gemm_ws_kernel<VPROJ, GATE> a step has two barriers: every wave multiplies a K-slice of the tile against the folded
+// key matrix, the partial scores meet in LDS, barrier, softmax -- and only then the value MFMAs start; all eight waves
+// sit through the score round trip.  Here wave w COPIES exactly the K-slice it scores: bytes [128 w, 128 w + 128) of every
+// (sample, modality) row go to its own slab of the LDS tile (six 1 KB LDS-DMA pieces of 8 rows x 128 B), so the moment its
+// own copy of tile s + 1 has landed (the end-of-step vmcnt wait it does anyway) it can form its partial scores of step
+// s + 1 -- no other wave's data is involved -- and park them in the other of two partial buffers.  The step's one barrier then
+// publishes tile and partials together, the softmax follows it directly and the MFMA phase starts without a second barrier.
+// LDS image of a slab: rows in modality-major order (row = 16 m + sample), 128 bytes each, 16-byte chunk c at
+// c ^ (sample & 7): the fragment reads of both uses (16 samples of one modality, chunk 4 (ks & 1) + lane group) are
+// bank-conflict free for ds_read_b128's lane grouping.
+// Measured (C2, same-box A/B, 3 pairs): value projection 118 -> 114 us, step -0.6 %: the second barrier was a small part
+// of the score phase; its MFMAs, the partial sums' trip through LDS and the softmax remain.
+template <int M_>
+__global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int rows_per_block, int nchunk) {
+    using X = Tr<BF16>;
+    constexpr int KT = 16, K = 512, CT = 2, KG = 2;
+    constexpr int SB = 128;                                        // slab row bytes (two K-steps)
+    constexpr int SLAB = 16 * M_ * SB;                             // one wave's slab of a tile
+    constexpr int TILE = 8 * SLAB;                                 // = 16 M rows x 1 KB
+    constexpr int CW = 32, BC = 256, NV = 8;
+    constexpr int GP = 8 * M_ * 256;                               // floats of one partial-score buffer
+    constexpr int NDMA = 16 * M_ * SB / 1024;                      // 1 KB pieces per wave and tile (M = 3: 6)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gpart = reinterpret_cast<float*>(smem + 2 * TILE);      // [2][8 waves][M][16 heads][16 samples]
+
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const int N = p.N, H = p.H;
+    unsigned int chunk_u, group_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(p.N / BC), chunk_u, group_u)) return;
+    const int ncol0 = (int)group_u * BC + CW * w;
+    const int64_t o_beg = (int64_t)chunk_u * rows_per_block;
+    const int64_t o_end = (o_beg + rows_per_block) < p.R ? (o_beg + rows_per_block) : p.R;
+    if (o_beg >= o_end) return;
+
+    const char* asrc = reinterpret_cast<const char*>(p.a);
+    // this wave's copy of a tile: piece i, lane l -> slab row 8 i + (l >> 3) = 16 m + sample, physical chunk l & 7
+    const unsigned int row_pitch = (unsigned)K * 2u;               // bytes of one (sample, modality) row
+    auto issue = [&](int64_t o0, int buf) {
+        const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
+        const char* src = asrc + o0 * M_ * (int64_t)row_pitch + SB * w;
+        char* dst0 = smem + buf * TILE + w * SLAB;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int rho = 8 * i + (lane >> 3), m = rho >> 4, b = rho & 15;
+            const int bc = b < ov ? b : ov - 1;
+            const unsigned int voff = (unsigned)(bc * M_ + m) * row_pitch + (unsigned)(((lane & 7) ^ (b & 7)) << 4);
+            const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(dst0 + 1024 * i);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst)
+                         : "memory", "m0");
+        }
+    };
+    issue(o_beg, 0);
+
+    const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w);
+    u32x4 wreg[KT][CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = ncol0 + 8 * (r16 >> 2) + 4 * c + (r16 & 3);
+        const unsigned short* wr = wsrc + (int64_t)n * K + 8 * lg;
+        const u32x4* wf = reinterpret_cast<const u32x4*>(p.w_frag) + ((int64_t)((ncol0 / CW) * CT + c) * KT) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = p.w_frag ? wf[ks * 64] : *reinterpret_cast<const u32x4*>(wr + 32 * ks);
+    }
+    float bias[NV];
+    {
+        const unsigned short* bs = reinterpret_cast<const unsigned short*>(p.bias);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) bias[j] = bs ? X::to_f32(bs[ncol0 + NV * lg + j]) : 0.f;
+    }
+    const int head = ncol0 / p.hd;
+    // operand read of (modality m, K-step ks) for this lane's sample: slab ks >> 1, row 16 m + r16, chunk 4 (ks & 1) + lg
+    int xoff[KG];
+#pragma unroll
+    for (int kk = 0; kk < KG; ++kk) xoff[kk] = r16 * SB + ((((4 * kk) + lg) ^ (r16 & 7)) << 4);
+
+    u32x4 ga[KG][2];                                               // score operands (rows of A hi / lo = heads) of this wave's K-steps
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+        const int ks = KG * w + kg;
+        ga[kg][0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.g_ahi) + (int64_t)r16 * K + 32 * ks + 8 * lg);
+        ga[kg][1] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.g_alo) + (int64_t)r16 * K + 32 * ks + 8 * lg);
+    }
+    unsigned int kp[M_], kp_next[M_];
+    {   // the first step's mask bytes by ordinary loads (hipcc counts them)
+        const int64_t b0 = (o_beg + r16) < o_end ? (o_beg + r16) : (o_end - 1);
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            kp[m] = p.g_kpm ? (unsigned int)p.g_kpm[b0 * M_ + m] : 0u;
+            kp_next[m] = 0u;
+        }
+    }
+    auto load_kp = [&](int64_t o0) {
+        if (p.g_kpm) {
+            const int64_t b = (o0 + r16) < o_end ? (o0 + r16) : (o_end - 1);
+            const uint8_t* kq = p.g_kpm + b * M_;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) asm volatile("global_load_ubyte %0, %1, off" : "+v"(kp_next[m]) : "v"(kq + m) : "memory");
+        }
+    };
+    // partial scores of the tile in `buf` from this wave's own slab -> partial buffer gp
+    auto scores = [&](int buf, float* gp) {
+        const char* sl = smem + buf * TILE + w * SLAB;
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            f32x4 gacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const u32x4 xf = *reinterpret_cast<const u32x4*>(sl + m * 16 * SB + xoff[kg]);
+                gacc = X::mma(ga[kg][0], xf, gacc);
+                gacc = X::mma(ga[kg][1], xf, gacc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gp[((w * M_ + m) * 16 + 4 * lg + r) * 16 + r16] = gacc[r];   // head 4 lg + r, sample r16
+        }
+    };
+    // the weights (and score operands) are used here so that hipcc retires their loads now, not inside the loop
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(wreg[ks][c]));
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) asm volatile("" : "+v"(ga[kg][0]), "+v"(ga[kg][1]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // own slab of the first tile landed
+    scores(0, gpart);
+
+    int cur = 0;
+    for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
+        const bool more = o0 + 16 < o_end;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's partial scores of this step are in LDS
+        __builtin_amdgcn_s_barrier();                              // tile and partials of this step visible; other buffers free
+        if (more) load_kp(o0 + 16);
+        // ---- softmax over the modalities for (this wave's head, this lane's sample); partial sums in wave order
+        float pm[M_];
+        {
+            const float* gp = gpart + cur * GP;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                float a = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) a += gp[((ww * M_ + m) * 16 + head) * 16 + r16];
+                if (kp[m] != 0u) a = -INFINITY;                    // torch functional.py:6554-6566
+                pm[m] = a;
+                mx = fmaxf(mx, a);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) { pm[m] = expf(pm[m] - mx); sum += pm[m]; }
+            const int64_t bq = o0 + r16;
+            const bool writer = lg == 0 && ncol0 % p.hd == 0 && bq < o_end;
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                pm[m] = pm[m] / sum;
+                if (writer) const_cast<float*>(p.probs)[(bq * H + head) * M_ + m] = pm[m];
+            }
+        }
+        // ---- products: modality-major items, operand reads PF items ahead; the next tile's copy goes out among the first
+        constexpr int NIT = M_ * KT, PF = 3;
+        const char* tb = smem + cur * TILE;
+        auto rd = [&](int i) -> u32x4 {
+            const int ks = i % KT, m = i / KT;
+            return *reinterpret_cast<const u32x4*>(tb + (ks >> 1) * SLAB + m * 16 * SB + xoff[ks & 1]);
+        };
+        f32x4 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float ov[NV];
+        unsigned int vpk[M_][NV / 2];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) ov[j] = 0.f;
+        u32x4 xf[PF + 1];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) xf[i] = rd(i);
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
+            if (i == NIT / 8 && more) issue(o0 + 16, cur ^ 1);
+            const int ks = i % KT;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[c]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+            if (ks == KT - 1) {
+                const int m = i / KT;
+                float v[NV];
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[4 * c + r] = acc[c][r] + bias[4 * c + r];
+                        ov[4 * c + r] = fmaf(pm[m], v[4 * c + r], ov[4 * c + r]);
+                    }
+#pragma unroll
+                for (int j = 0; j < NV / 2; ++j) vpk[m][j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slab of the next tile (and its mask bytes) landed
+#pragma unroll
+        for (int m = 0; m < M_; ++m) { asm volatile("" : "+v"(kp_next[m])); kp[m] = p.g_kpm ? kp_next[m] : 0u; }
+        if (more) scores(cur ^ 1, gpart + (cur ^ 1) * GP);         // next step's partial scores, from this wave's own slab
+        const int64_t b = o0 + r16;
+        if (b < o_end) {
+            if (p.v_out) {
+#pragma unroll
+                for (int m = 0; m < M_; ++m)
+                    store_packed<CT>(reinterpret_cast<unsigned short*>(p.v_out) + (b * M_ + m) * N + ncol0 + NV * lg, vpk[m]);
+            }
+            if (p.out_f32) store_cols_f32<CT>(reinterpret_cast<float*>(p.c) + b * N + ncol0 + NV * lg, ov);
+            else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + NV * lg, ov);
+        }
+    }
+}
+
+template <int M_>
+void launch_vproj_slab(const GemmNtArgs& a, hipStream_t s) {
+    const size_t smem = (size_t)2 * 16 * M_ * 1024 + (size_t)2 * 8 * M_ * 256 * sizeof(float);
+    const int groups = a.N / 256;
+    int64_t chunks = 256 / groups;
+    if (chunks < 1) chunks = 1;
+    int64_t rpb = (a.R + chunks - 1) / chunks;
+    rpb = (rpb + 15) / 16 * 16;
+    const int64_t nchunk = (a.R + rpb - 1) / rpb;
+    dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
+    auto kern = vproj_slab_kernel<M_>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a, (int)rpb, (int)nchunk);
+}
+
 template <int KT, int MODE, int M_, bool GATE>
 void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     constexpr int K = 32 * KT;
@@ -938,6 +1173,10 @@ void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     const int64_t nchunk = (a.R + rpb - 1) / rpb;
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
     if (GATE) smem += (size_t)8 * M_ * 256 * sizeof(float);
+    if (MODE == WS_VPROJ && GATE && KT == 16 && M_ <= 3) {         // hot shape (K = 512): the column-slab form
+        static const int no_slab = getenv("AECF_NO_SLAB") ? atoi(getenv("AECF_NO_SLAB")) : 0;      // A/B timing only
+        if (!no_slab) { launch_vproj_slab<(M_ <= 3 ? M_ : 3)>(a, s); return; }
+    }
     auto kern = gemm_ws_kernel<KT, MODE, M_, GATE, CT>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
