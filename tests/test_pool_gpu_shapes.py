@@ -134,9 +134,9 @@ print("RESULT " + json.dumps(dict(errs=errs, agree=agree)))
 
 
 @pytest.mark.parametrize("knobs", [{"AECF_NO_WS": "1"}, {"AECF_NO_GATE_FUSION": "1"}, {"AECF_NO_WIDE_TN": "1"},
-                                   {"AECF_GRAPH": "0"}, {"AECF_FUSED_FWD": "1"}, {"AECF_PM": "1"}],
+                                   {"AECF_GRAPH": "0"}, {"AECF_FUSED_FWD": "1"}, {"AECF_PM": "1"}, {"AECF_NO_SLAB": "1"}],
                          ids=["tiled", "separate_gate", "narrow_batch_reduction", "plain_launches", "one_kernel_forward",
-                              "matrix_pipe_pooling"])
+                              "matrix_pipe_pooling", "two_barrier_gate"])
 def test_bf16_fallback_kernels_at_the_hot_path_shape(knobs):
     """The kernels that serve shapes the weight-stationary engine does not take (tiled NT GEMM, per-modality value
     projection, stand-alone gate, tiled dx) stay correct at d=512 / 8 heads / M=3: the library's A/B switches route the
