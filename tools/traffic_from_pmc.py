@@ -6,6 +6,7 @@ import csv, glob, json, re, sqlite3, sys, collections
 STAGE = [  # (regex on the kernel name, stage)
     (r"gate_fwd_kernel", "fwd.gate"),
     (r"gemm_ws_kernel<\d+, [12],", "fwd.vproj"), (r"gate_stats_kernel", "fwd.vproj"), (r"vproj_modal_kernel", "fwd.vproj"),
+    (r"vproj_slab_kernel", "fwd.vproj"),
     (r"gemm_ws_kernel<\d+, 0,", "plain_nt"), (r"gemm_nt_kernel", "plain_nt"),
     (r"gemm_tn_tr_kernel<1, false", "bwd.dw_out"),
     (r"dscore_v_kernel", "bwd.dscore"), (r"dsu_ws_kernel", "bwd.dscore"), (r"row_fwd_kernel", "fwd.vproj"),
