@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AECF_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
 LIB_PATH = os.environ.get("AECF_LIB_PATH") or os.path.join(_HERE, "lib", "libaecf_hip.so")
 
-AECF_ABI_VERSION = 5
+AECF_ABI_VERSION = 6
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_PRECISE = 1
@@ -131,6 +131,13 @@ _SYMBOLS = [
     ("aecf_l2norm_forward", c_int, [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_l2norm_backward", c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_nce_workspace_bytes", c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    ("aecf_nce_stream_workspace_bytes", c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    ("aecf_nce_sym_workspace_bytes", c_size_t, [c_int64, c_int64, c_int32]),
+    ("aecf_nce_sym_pass1", c_int,
+     [c_int64, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    ("aecf_nce_sym_pass2", c_int,
+     [c_int64, c_int64, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+      c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     ("aecf_nce_fwd_bwd", c_int,
      [c_int64, c_int64, c_int64, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -782,14 +782,53 @@ int aecf_loss_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d,
                       float* d_entropy, void* workspace, size_t workspace_bytes, void* stream) {
     if (rows <= 0 || cols <= 0 || d <= 0 || temperature <= 0.f || n_entropy < 0) return AECF_ERR_BAD_DIMS;
     if (row_offset < 0 || row_offset + rows > cols) return AECF_ERR_BAD_DIMS;
-    if (!nce_flash_supported(AECF_BF16, d)) return AECF_ERR_UNSUPPORTED;
     if (!q || !k || !loss_rows || !dq || !dk || !workspace) return AECF_ERR_NULL_POINTER;
     if (n_entropy > 0 && (!entropy || !entropy_loss)) return AECF_ERR_NULL_POINTER;
-    if (workspace_bytes < nce_flash_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
     const double max_ent = last_seq_len > 1 ? log((double)last_seq_len) : 0.0;       // ref :301-308
-    launch_nce_flash(rows, cols, row_offset, d, 1.0f / temperature, coef, q, k, loss_rows, dq, dk, workspace,
-                     n_entropy > 0 ? entropy : nullptr, n_entropy, (float)(max_ent * (double)entropy_target), entropy_upstream,
-                     d_entropy, entropy_loss, (hipStream_t)stream);
+    const float ent_t = (float)(max_ent * (double)entropy_target);
+    const float* ent = n_entropy > 0 ? entropy : nullptr;
+    if (nce_gemm_supported(AECF_BF16, d, temperature) && workspace_bytes >= nce_gemm_workspace_bytes(rows, cols, d)) {
+        launch_nce_gemm_pass1(rows, cols, d, 1.0f / temperature, q, k, workspace, nullptr, (hipStream_t)stream);
+        launch_nce_gemm_pass2(rows, cols, row_offset, d, 1.0f / temperature, coef, 0, q, k, nullptr, workspace, loss_rows, dq, dk,
+                              ent, n_entropy, ent_t, entropy_upstream, d_entropy, entropy_loss, (hipStream_t)stream);
+        return launch_status();
+    }
+    if (!nce_flash_supported(AECF_BF16, d)) return AECF_ERR_UNSUPPORTED;
+    if (workspace_bytes < nce_flash_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
+    launch_nce_flash(rows, cols, row_offset, d, 1.0f / temperature, coef, q, k, loss_rows, dq, dk, workspace, ent, n_entropy, ent_t,
+                     entropy_upstream, d_entropy, entropy_loss, (hipStream_t)stream);
+    return launch_status();
+}
+
+size_t aecf_nce_sym_workspace_bytes(int64_t rows, int64_t cols, int32_t d) {
+    if (rows <= 0 || cols <= 0 || d <= 0 || d % 64 != 0) return 0;
+    return nce_gemm_workspace_bytes(rows, cols, d);
+}
+
+int aecf_nce_sym_pass1(int64_t rows, int64_t cols, int32_t d, float temperature, const void* a, const void* b, void* workspace,
+                       size_t workspace_bytes, float* col_sums, void* stream) {
+    if (rows <= 0 || cols <= 0 || d <= 0 || temperature <= 0.f || rows > cols) return AECF_ERR_BAD_DIMS;
+    if (!nce_gemm_supported(AECF_BF16, d, temperature)) return AECF_ERR_UNSUPPORTED;
+    if (!a || !b || !workspace || !col_sums) return AECF_ERR_NULL_POINTER;
+    if (workspace_bytes < nce_gemm_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
+    launch_nce_gemm_pass1(rows, cols, d, 1.0f / temperature, a, b, workspace, col_sums, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_nce_sym_pass2(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef, const void* a,
+                       const void* b, const float* col_sums, void* workspace, size_t workspace_bytes, float* loss_rows, float* da,
+                       float* db, int64_t n_entropy, int32_t last_seq_len, float entropy_target, const float* entropy,
+                       float entropy_upstream, float* entropy_loss, float* d_entropy, void* stream) {
+    if (rows <= 0 || cols <= 0 || d <= 0 || temperature <= 0.f || n_entropy < 0) return AECF_ERR_BAD_DIMS;
+    if (row_offset < 0 || row_offset + rows > cols) return AECF_ERR_BAD_DIMS;
+    if (!nce_gemm_supported(AECF_BF16, d, temperature)) return AECF_ERR_UNSUPPORTED;
+    if (!a || !b || !col_sums || !workspace || !loss_rows || !da || !db) return AECF_ERR_NULL_POINTER;
+    if (n_entropy > 0 && (!entropy || !entropy_loss)) return AECF_ERR_NULL_POINTER;
+    if (workspace_bytes < nce_gemm_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
+    const double max_ent = last_seq_len > 1 ? log((double)last_seq_len) : 0.0;       // ref :301-308
+    launch_nce_gemm_pass2(rows, cols, row_offset, d, 1.0f / temperature, coef, 1, a, b, col_sums, workspace, loss_rows, da, db,
+                          n_entropy > 0 ? entropy : nullptr, n_entropy, (float)(max_ent * (double)entropy_target), entropy_upstream,
+                          d_entropy, entropy_loss, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -843,9 +882,15 @@ int aecf_l2norm_backward(int64_t n, int32_t d, int32_t dtype, const void* zn, co
 
 size_t aecf_nce_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype) {
     if (rows <= 0 || cols <= 0 || d <= 0) return 0;
+    if (nce_gemm_supported(dtype, d, 1.0f)) return nce_gemm_workspace_bytes(rows, cols, d);
     if (nce_flash_supported(dtype, d)) return nce_flash_workspace_bytes(rows, cols, d);
     const size_t es = esize(dtype);
     return align_up((size_t)rows * cols * 4) + align_up((size_t)rows * cols * es) + align_up((size_t)d * cols * es);
+}
+
+size_t aecf_nce_stream_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype) {
+    if (rows <= 0 || cols <= 0 || d <= 0 || !nce_flash_supported(dtype, d)) return 0;
+    return nce_flash_workspace_bytes(rows, cols, d);
 }
 
 int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, int32_t dtype, float temperature,
@@ -855,6 +900,12 @@ int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, 
     if (row_offset < 0 || row_offset + rows > cols) return AECF_ERR_BAD_DIMS;
     if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
     if (!q || !k || !loss_rows || !dq || !dk || !workspace) return AECF_ERR_NULL_POINTER;
+    if (nce_gemm_supported(dtype, d, temperature) && workspace_bytes >= nce_gemm_workspace_bytes(rows, cols, d)) {
+        launch_nce_gemm_pass1(rows, cols, d, 1.0f / temperature, q, k, workspace, nullptr, (hipStream_t)stream);
+        launch_nce_gemm_pass2(rows, cols, row_offset, d, 1.0f / temperature, coef, 0, q, k, nullptr, workspace, loss_rows, dq, dk,
+                              nullptr, 0, 0.f, 0.f, nullptr, nullptr, (hipStream_t)stream);
+        return launch_status();
+    }
     if (nce_flash_supported(dtype, d)) {         // streaming form: any rows / cols, workspace O(rows d)
         if (workspace_bytes < nce_flash_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
         launch_nce_flash(rows, cols, row_offset, d, 1.0f / temperature, coef, q, k, loss_rows, dq, dk, workspace, nullptr, 0,

@@ -54,7 +54,7 @@ class _NceDirection(torch.autograd.Function):
     Forward and both gradients come out of the same call (the gradients are linear in the upstream scalar)."""
 
     @staticmethod
-    def forward(ctx, q, k_all, row_offset, temperature, coef):
+    def forward(ctx, q, k_all, row_offset, temperature, coef, low_memory=False):
         lib = _lib.load()
         rows, d = q.shape
         cols = k_all.shape[0]
@@ -64,7 +64,13 @@ class _NceDirection(torch.autograd.Function):
         loss_rows = torch.empty(rows, dtype=torch.float32, device=dev)
         dq = torch.empty(rows, d, dtype=torch.float32, device=dev)
         dk = torch.empty(cols, d, dtype=torch.float32, device=dev)
-        ws_bytes = lib.aecf_nce_workspace_bytes(rows, cols, d, _DTYPES[dt])
+        # the workspace handed over selects the implementation (include/aecf_hip.h): rows x cols bf16 -> tile GEMMs,
+        # O(rows d) -> the streaming form
+        ws_bytes = lib.aecf_nce_stream_workspace_bytes(rows, cols, d, _DTYPES[dt]) if low_memory else 0
+        if ws_bytes == 0:
+            if low_memory:
+                raise NotImplementedError(f"aecf_amd: no streaming InfoNCE for dtype {dt}, d = {d}")
+            ws_bytes = lib.aecf_nce_workspace_bytes(rows, cols, d, _DTYPES[dt])
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.aecf_nce_fwd_bwd(rows, cols, row_offset, d, _DTYPES[dt], temperature, coef, _ptr(qc), _ptr(kc),
                                         _ptr(loss_rows), _ptr(dq), _ptr(dk), _ptr(ws), ws_bytes, _stream()),
@@ -77,7 +83,60 @@ class _NceDirection(torch.autograd.Function):
     def backward(ctx, dloss):
         dq, dk = ctx.saved_tensors
         g = dloss.to(torch.float32)
-        return (dq * g).to(ctx.dtypes[0]), (dk * g).to(ctx.dtypes[1]), None, None, None
+        return (dq * g).to(ctx.dtypes[0]), (dk * g).to(ctx.dtypes[1]), None, None, None, None
+
+
+class _NceSymmetric(torch.autograd.Function):
+    """aecf_nce_sym_pass1 / _pass2: BOTH directions of the symmetric InfoNCE from one block of logits (local rows of view a
+    against the gathered rows of view b).  The column sums of the exponentials are the one thing ranks exchange (one
+    all-reduce of `cols` floats between the passes); the gradient on the gathered keys is this rank's share (the caller's
+    all-gather backward reduce-scatters it).  Optionally carries CurriculumMasking.entropy_loss (ref aecf/AECFLayer.py:285-314)
+    in the same call.  Returns (this rank's rows' share of the loss, entropy loss)."""
+
+    @staticmethod
+    def forward(ctx, a, b_all, entropy, row_offset, temperature, coef, group, last_seq_len, entropy_target):
+        lib = _lib.load()
+        rows, d = a.shape
+        cols = b_all.shape[0]
+        dev = a.device
+        ac, bc = a.detach().to(torch.bfloat16).contiguous(), b_all.detach().to(torch.bfloat16).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws_bytes = lib.aecf_nce_sym_workspace_bytes(rows, cols, d)
+        if ws_bytes == 0:
+            raise NotImplementedError(f"aecf_amd: symmetric InfoNCE needs d % 64 == 0, got d = {d}")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        col_sums = torch.empty(cols, **f32)
+        _lib.check(lib.aecf_nce_sym_pass1(rows, cols, d, temperature, _ptr(ac), _ptr(bc), _ptr(ws), ws_bytes, _ptr(col_sums),
+                                          _stream()), "aecf_nce_sym_pass1")
+        if dp.world_info(group)[1] > 1:
+            torch.distributed.all_reduce(col_sums, group=group)
+        loss_rows, da, db = torch.empty(rows, **f32), torch.empty(rows, d, **f32), torch.empty(cols, d, **f32)
+        if entropy is not None:
+            ent = entropy.detach().to(torch.float32).contiguous().reshape(-1)
+            ent_loss, dent = torch.zeros(1, **f32), torch.empty(ent.numel(), **f32)
+            n_ent, p_ent, p_el, p_de = ent.numel(), _ptr(ent), _ptr(ent_loss), _ptr(dent)
+        else:
+            ent_loss, dent, n_ent, p_ent, p_el, p_de = torch.zeros(1, **f32), None, 0, None, None, None
+        _lib.check(lib.aecf_nce_sym_pass2(rows, cols, row_offset, d, temperature, coef, _ptr(ac), _ptr(bc), _ptr(col_sums),
+                                          _ptr(ws), ws_bytes, _ptr(loss_rows), _ptr(da), _ptr(db), n_ent, last_seq_len,
+                                          entropy_target, p_ent, 1.0, p_el, p_de, _stream()), "aecf_nce_sym_pass2")
+        ctx.save_for_backward(da, db, *([dent] if dent is not None else []))
+        ctx.meta = (a.dtype, b_all.dtype, None if entropy is None else (entropy.dtype, entropy.shape))
+        return loss_rows.sum() * coef, ent_loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_nce, d_ent):
+        da, db = ctx.saved_tensors[:2]
+        ad, bd, em = ctx.meta
+        g = d_nce.to(torch.float32)
+        g_ent = None
+        if em is not None:
+            g_ent = (ctx.saved_tensors[2] * d_ent.to(torch.float32)).reshape(em[1]).to(em[0])
+        return (da * g).to(ad), (db * g).to(bd), g_ent, None, None, None, None, None, None
+
+
+def _sym_supported(z: torch.Tensor, temperature: float) -> bool:
+    return z.dtype == torch.bfloat16 and z.shape[1] % 64 == 0 and temperature >= 0.025
 
 
 class _LossDirection(torch.autograd.Function):
@@ -125,6 +184,10 @@ def contrastive_entropy_loss(za: torch.Tensor, zb: torch.Tensor, masking: Curric
     na, nb = l2_normalize(za), l2_normalize(zb)
     coef = 0.5 / float(za.shape[0])
     seq_len = masking._last_seq_len if hasattr(masking, "_last_seq_len") else 2
+    if _sym_supported(za, temperature):
+        l_nce, l_ent = _NceSymmetric.apply(na, nb, entropy, 0, float(temperature), coef, None, int(seq_len),
+                                           float(masking.entropy_target))
+        return contrastive_weight * l_nce + entropy_weight * l_ent.to(za.dtype)
     l_ab, l_ent = _LossDirection.apply(na, nb, entropy, 0, float(temperature), coef, int(seq_len),
                                        float(masking.entropy_target))
     l_ba = _NceDirection.apply(nb, na, 0, float(temperature), coef)
@@ -138,8 +201,9 @@ def l2_normalize(z: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
 
 def info_nce(za: torch.Tensor, zb: torch.Tensor, temperature: float = 0.07, group=None) -> torch.Tensor:
     """Symmetric InfoNCE between the local rows of two views with negatives from every rank of ``group``.
-    ``za``, ``zb``: [b_local, d] on a ROCm device.  bfloat16 with d in {128, 256, 384, 512, 768, 1024} runs the streaming
-    form (no [rows, cols] logits, any row counts); otherwise d % 64 == 0 and total rows over ranks % 64 == 0."""
+    ``za``, ``zb``: [b_local, d] on a ROCm device.  bfloat16 with d % 64 == 0 (temperature >= 0.025) runs the symmetric tile-GEMM
+    form: both directions from ONE block of logits, exponentials kept as bf16 [b_local, b_all] (any row counts); float32:
+    d % 64 == 0 and total rows over ranks % 64 == 0."""
     _require_device(za, "za")
     _require_device(zb, "zb")
     if za.shape != zb.shape or za.dim() != 2:
@@ -148,9 +212,9 @@ def info_nce(za: torch.Tensor, zb: torch.Tensor, temperature: float = 0.07, grou
         raise NotImplementedError(f"aecf_amd: dtype {za.dtype} is not supported (bfloat16 / float32 only)")
     rank, world = dp.world_info(group)
     na, nb = l2_normalize(za), l2_normalize(zb)
-    na_all = dp.all_gather_rows(na, group) if world > 1 else na
+    sym = _sym_supported(za, temperature)
     nb_all = dp.all_gather_rows(nb, group) if world > 1 else nb
-    b_all = na_all.shape[0]
+    b_all = nb_all.shape[0]
     if world > 1:
         sizes = torch.tensor([za.shape[0]], device=za.device)
         all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
@@ -159,9 +223,15 @@ def info_nce(za: torch.Tensor, zb: torch.Tensor, temperature: float = 0.07, grou
     else:
         offset = 0
     coef = 0.5 / float(b_all)
-    l_ab = _NceDirection.apply(na, nb_all, offset, float(temperature), coef)
-    l_ba = _NceDirection.apply(nb, na_all, offset, float(temperature), coef)
-    share = l_ab + l_ba                  # this rank's rows' share of the global objective
+    if sym:
+        # both directions from the one block of logits this rank owns (its rows of view a against every row of view b):
+        # view a is never gathered, one all-reduce of b_all floats replaces the second direction's pass
+        share, _ = _NceSymmetric.apply(na, nb_all, None, offset, float(temperature), coef, group, 2, 0.0)
+    else:
+        na_all = dp.all_gather_rows(na, group) if world > 1 else na
+        l_ab = _NceDirection.apply(na, nb_all, offset, float(temperature), coef)
+        l_ba = _NceDirection.apply(nb, na_all, offset, float(temperature), coef)
+        share = l_ab + l_ba              # this rank's rows' share of the global objective
     if world == 1:
         return share
     # Data-parallel convention (dp.FlatGradBucket.all_reduce(average=True)): gradients are AVERAGED over ranks, so

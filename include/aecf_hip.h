@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AECF_ABI_VERSION 5
+#define AECF_ABI_VERSION 6
 
 typedef enum aecf_status {
     AECF_OK = 0,
@@ -333,11 +333,19 @@ int aecf_l2norm_backward(int64_t n, int32_t d, int32_t dtype, const void* zn, co
  *   loss_rows[i] = logsumexp_j(q_i.k_j / T) - q_i.k_pos / T                       float32 [rows]
  *   dq = coef/T * (softmax - onehot) k          float32 [rows,d]
  *   dk = coef/T * (softmax - onehot)^T q        float32 [cols,d]   (sum over ranks is the caller's reduce-scatter)
- * bf16 with d in {128, 256, 384, 512, 768, 1024}: streaming ("flash") form -- the [rows, cols] logits are never
- * materialised: key tiles stream through LDS under an online max / sum per row (the gradient on q is the attention
- * output with V = K), a second streaming pass forms dk from the saved log-sum-exp; any rows / cols, workspace
- * O(rows d).  Otherwise (float32, other d): materialising form, d % 64 == 0 and cols % 64 == 0. */
+ * Two implementations, chosen by the workspace the caller hands over (the caller owns the memory):
+ *   * tile-GEMM form (bf16, d % 64 == 0, temperature >= 0.025; workspace aecf_nce_workspace_bytes = rows x cols bf16 + O(rows
+ *     + cols) floats): E = exp((q.k - 1)/T) is written once as bf16, its row sums come out of the same GEMM epilogue, the
+ *     softmax weights are formed in place and dq / dk are two more tile GEMMs (transposed LDS reads: no transposed copies).
+ *     6 rows cols d flops.  Rows of q and k MUST have L2 norm <= 1 (+ bf16 rounding): 1/T is used as the shift of every exponent.
+ *   * streaming ("flash") form (bf16, d in {128, 256, 384, 512, 768, 1024}; workspace aecf_nce_stream_workspace_bytes =
+ *     O(rows d)): the [rows, cols] logits are never materialised -- key tiles stream through LDS under an online max / sum per
+ *     row, a second streaming pass forms dk from the saved log-sum-exp.  8 rows cols d flops; any norms, any temperature.
+ *   A workspace of at least aecf_nce_workspace_bytes selects the first, a smaller one of at least
+ *   aecf_nce_stream_workspace_bytes the second.  Otherwise (float32, other d): materialising float32 form, d % 64 == 0 and
+ *   cols % 64 == 0. */
 size_t aecf_nce_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype);
+size_t aecf_nce_stream_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype);   /* 0: no streaming form */
 int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, int32_t dtype,
                      float temperature, float coef, const void* q, const void* k, float* loss_rows,
                      float* dq, float* dk, void* workspace, size_t workspace_bytes, void* stream);
@@ -347,11 +355,34 @@ int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, 
  * aecf_nce_fwd_bwd (bf16, streaming form) and, riding in its row-combine launch, CurriculumMasking.entropy_loss forward +
  * backward (ref aecf/AECFLayer.py:285-314) on entropy [n_entropy] float32:
  *   entropy_loss[0] = mean((nan_to_num(H) - log(last_seq_len) * entropy_target)^2), d_entropy = d loss / dH * entropy_upstream.
- * n_entropy == 0: contrastive term only.  Workspace: aecf_nce_workspace_bytes(rows, cols, d, AECF_BF16). */
+ * n_entropy == 0: contrastive term only.  Workspace: aecf_nce_workspace_bytes(rows, cols, d, AECF_BF16) (tile-GEMM form) or
+ * aecf_nce_stream_workspace_bytes (streaming form), as for aecf_nce_fwd_bwd. */
 int aecf_loss_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef,
                       const void* q, const void* k, float* loss_rows, float* dq, float* dk, int64_t n_entropy,
                       int32_t last_seq_len, float entropy_target, const float* entropy, float entropy_upstream,
                       float* entropy_loss, float* d_entropy, void* workspace, size_t workspace_bytes, void* stream);
+
+
+/* BOTH directions of the symmetric InfoNCE from ONE block of logits (build-defined, as above): local rows a [rows,d] (global
+ * indices row_offset .. row_offset + rows) against all gathered keys b [cols,d], unit-norm bf16 rows, d % 64 == 0, T >= 0.025:
+ *   L = coef * sum_i [ lse_j(a_i.b_j/T) - a_i.b_pos/T ]  +  coef * sum_i [ lse_i'(a_i'.b_pos/T) - a_i.b_pos/T ],  pos = row_offset + i
+ * The second term's softmax runs down the COLUMNS of the global logits; a rank holds only its row block, so the column sums of
+ * E = exp((a.b - 1)/T) are the one quantity ranks exchange:
+ *   pass1: E (bf16, workspace), its row sums (workspace), and THIS rank's column sums col_sums [cols] (float32)
+ *   caller: all-reduce (sum) of col_sums over the ranks (nothing to do on one rank)
+ *   pass2: loss_rows[i] = both terms of local row i (float32 [rows]); da = dL/da [rows,d]; db = this rank's share of dL/db
+ *          [cols,d] (the sum over ranks is the caller's reduce-scatter); optionally CurriculumMasking.entropy_loss forward +
+ *          backward riding in one of its launches (arguments as aecf_loss_fwd_bwd; n_entropy == 0: off).
+ * 6 rows cols d MFMA flops for both directions (2 for the logits, 2 + 2 for the gradient products through transposed LDS
+ * reads) against 16 rows cols d for two calls of the streaming form.  Workspace: rows x cols bf16 + O(rows + cols) floats. */
+size_t aecf_nce_sym_workspace_bytes(int64_t rows, int64_t cols, int32_t d);
+int aecf_nce_sym_pass1(int64_t rows, int64_t cols, int32_t d, float temperature, const void* a, const void* b,
+                       void* workspace, size_t workspace_bytes, float* col_sums, void* stream);
+int aecf_nce_sym_pass2(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef,
+                       const void* a, const void* b, const float* col_sums, void* workspace, size_t workspace_bytes,
+                       float* loss_rows, float* da, float* db, int64_t n_entropy, int32_t last_seq_len,
+                       float entropy_target, const float* entropy, float entropy_upstream, float* entropy_loss,
+                       float* d_entropy, void* stream);
 
 #ifdef __cplusplus
 }

@@ -103,10 +103,12 @@ def _nce_reference(q, k, off, T, coef, rows_sel=None, cols_sel=None):
     return loss, dq, dk
 
 
+@pytest.mark.parametrize("low_memory", [False, True], ids=["gemm", "stream"])
 @pytest.mark.parametrize("rows,cols,off,d", [(128, 128, 0, 128), (100, 333, 57, 256), (640, 2048, 1000, 512),
                                              (97, 1500, 3, 768), (64, 700, 600, 1024), (200, 200, 0, 384)])
-def test_flash_nce_matches_float32_reference(rows, cols, off, d):
-    """Streaming InfoNCE (aecf_nce_flash.hip) against float32 torch math on the same bf16 inputs: ragged row / column
+def test_flash_nce_matches_float32_reference(rows, cols, off, d, low_memory):
+    """One InfoNCE direction -- tile-GEMM form (aecf_nce_gemm.hip, the default) and streaming form (aecf_nce_flash.hip, chosen
+    by handing over the O(rows d) workspace) -- against float32 torch math on the same bf16 inputs: ragged row / column
     counts (no % 64 restriction), key splits, every supported width, positives at an offset (a data-parallel shard)."""
     from aecf_amd.losses import _NceDirection, l2_normalize
     dev = torch.device("cuda:0")
@@ -117,7 +119,7 @@ def test_flash_nce_matches_float32_reference(rows, cols, off, d):
         k[off:off + rows] = (0.8 * q.detach().float() + 0.6 * k[off:off + rows].float()).to(torch.bfloat16)   # real positives
     k.requires_grad_(True)
     T, coef = 0.07, 0.5 / cols
-    out = _NceDirection.apply(q, k, off, T, coef)
+    out = _NceDirection.apply(q, k, off, T, coef, low_memory)
     out.backward()
     loss, dq, dk = _nce_reference(q.detach(), k.detach(), off, T, coef)
     assert abs(float(out) - float(loss.sum() * coef)) < 2e-3 * abs(float(loss.sum() * coef))
@@ -126,8 +128,8 @@ def test_flash_nce_matches_float32_reference(rows, cols, off, d):
 
 
 def test_flash_nce_config3_size():
-    """BASELINE configs[2]: 8192 local rows against 65536 gathered keys, d = 768, bf16 -- 2.1 GB of float32 logits that
-    are never materialised (workspace O(rows d): ~50 MB).  Checked against float32 torch math (row-chunked) and, on a
+    """BASELINE configs[2]: 8192 local rows against 65536 gathered keys, d = 768, bf16 -- the STREAMING form: 2.1 GB of
+    float32 logits that are never materialised (workspace O(rows d): ~50 MB).  Checked against float32 torch math (row-chunked) and, on a
     row subset, against the CPU oracle's closed form."""
     from aecf_amd import _lib
     from aecf_amd.losses import _NceDirection, l2_normalize
@@ -138,14 +140,14 @@ def test_flash_nce_config3_size():
     q = l2_normalize(torch.randn(rows, d, device=dev, generator=g).to(torch.bfloat16)).detach()
     k = l2_normalize(torch.randn(cols, d, device=dev, generator=g).to(torch.bfloat16)).detach()
     k[off:off + rows] = (0.9 * q.float() + 0.45 * k[off:off + rows].float()).to(torch.bfloat16)
-    ws = _lib.load().aecf_nce_workspace_bytes(rows, cols, d, _lib.AECF_BF16)
+    ws = _lib.load().aecf_nce_stream_workspace_bytes(rows, cols, d, _lib.AECF_BF16)
     assert ws < 64 << 20, ws                                       # O(rows d), not O(rows cols)
     q.requires_grad_(True)
     k.requires_grad_(True)
     coef = 0.5 / cols
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
-    out = _NceDirection.apply(q, k, off, T, coef)
+    out = _NceDirection.apply(q, k, off, T, coef, True)
     out.backward()
     torch.cuda.synchronize()
     assert torch.cuda.max_memory_allocated() - base < 1200 << 20   # outputs + gradients + workspace; no logits

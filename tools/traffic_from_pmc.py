@@ -43,7 +43,8 @@ def main():
             if re.search(rx, k):
                 # kernels launched more than once per step under one name (the two plain NT GEMMs) are averaged per launch
                 stages[st] += b
-                kernels[re.sub(r"\(.*", "", k)[:80]] = dict(stage=st, bytes_per_launch=b, fetch_kb=fetch[k],
+                short = re.sub(r"\(anonymous namespace\)::", "", k).replace("void aecf::", "").replace("aecf::", "")
+                kernels[re.sub(r"\(.*", "", short)[:80]] = dict(stage=st, bytes_per_launch=b, fetch_kb=fetch[k],
                                                            write_kb=write.get(k, 0.0), launches=nf[k])
                 break
     if "plain_nt" in stages:
