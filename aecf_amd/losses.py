@@ -194,6 +194,26 @@ def contrastive_entropy_loss(za: torch.Tensor, zb: torch.Tensor, masking: Curric
     return contrastive_weight * (l_ab + l_ba) + entropy_weight * l_ent.to(za.dtype)
 
 
+def gathered_contrastive_entropy_loss(za: torch.Tensor, nb_all: torch.Tensor, row_offset: int, masking: CurriculumMasking,
+                                      entropy: torch.Tensor, temperature: float = 0.07, entropy_weight: float = 0.01,
+                                      contrastive_weight: float = 1.0, group=None) -> torch.Tensor:
+    """The loss side of a data-parallel step in ONE operator: this rank's rows ``za`` [b_local, d] (bf16, not yet normalised)
+    against the unit-norm rows of the other view from EVERY rank ``nb_all`` [b_all, d] (``dp.all_gather_rows(l2_normalize(zb))``:
+    its backward reduce-scatters the share of the gradient this call returns), positives at ``row_offset + i``; both InfoNCE
+    directions from the one block of logits (``aecf_nce_sym_pass1/2``; the column sums are all-reduced over ``group`` between
+    the passes) plus ``entropy_weight * masking.entropy_loss(entropy)`` riding in the same call.  Returns this rank's share of
+    ``contrastive_weight * L_nce`` (coef = 0.5 / b_all) plus the entropy term."""
+    _require_device(za, "za")
+    if not _sym_supported(za, temperature):
+        raise NotImplementedError("aecf_amd: the gathered contrastive loss needs bfloat16 rows with d % 64 == 0 and temperature >= 0.025")
+    na = l2_normalize(za)
+    coef = 0.5 / float(nb_all.shape[0])
+    seq_len = masking._last_seq_len if hasattr(masking, "_last_seq_len") else 2
+    l_nce, l_ent = _NceSymmetric.apply(na, nb_all, entropy, int(row_offset), float(temperature), coef, group, int(seq_len),
+                                       float(masking.entropy_target))
+    return contrastive_weight * l_nce + entropy_weight * l_ent.to(za.dtype)
+
+
 def l2_normalize(z: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     _require_device(z, "z")
     return _L2Norm.apply(z, float(eps))

@@ -12,6 +12,12 @@ gives every rank its own B samples, `--scaling strong` shards the global B=65536
 gradients (4E^2+5E values) are all-reduced over RCCL inside the step and every rank consumes ITS rows of one global
 uniform tensor for the curriculum mask (N-rank masks == 1-rank masks).
 
+`--config c3 --contrastive` (BASELINE configs[2]: "2-modality d=768 with cross-batch contrastive all-gather"): the step is the
+pool forward on the rank's [8192, 2, 768] rows, the symmetric InfoNCE of the fused rows against the 65536 gathered rows of the
+paired view (both directions from one logits block, entropy regulariser riding along: losses.gathered_contrastive_entropy_loss)
+and the backward through both.  N = 1 emulates the all-gather with resident unit-norm keys (this rank's 8192 rows of the
+paired view sit at their offset among them); N > 1 gathers them (dp.all_gather_rows) every step.
+
 `python bench.py --gpus N` without a launcher starts the N ranks itself (child processes, started before this process
 touches the GPU) and relays rank 0's JSON line; under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 """
@@ -41,8 +47,11 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16
-PROFILE_TAG = "r02"              # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
-STAGE_PASS_STEPS = 30            # steps of the per-stage HIP-event pass (roofline), run before the warmup
+PROFILE_TAG = "r03"              # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
+STAGE_PASS_STEPS = 30            # steps of the per-stage HIP-event pass (roofline), run AFTER the timed region (warm)
+SETTLE_STEPS = 30                # untimed steps of a fresh process before the W warm-up steps (stated in the line)
+NCE_KEYS = 65536                 # --contrastive: gathered keys of configs[2] (8 ranks x 8192 rows)
+NCE_TEMPERATURE = 0.07
 
 
 def make_inputs(cfg, device, seed_offset=0):
@@ -153,9 +162,34 @@ def stage_model(cfg):
     }
 
 
+def physical_cores():
+    """(socket, core) pairs of /proc/cpuinfo that this process may run on -- hardware threads are not cores."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        cores, cpu, phys = set(), None, 0
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k = k.strip()
+                if k == "processor":
+                    cpu = int(v)
+                elif k == "physical id":
+                    phys = int(v)
+                elif k == "core id" and cpu in allowed:
+                    cores.add((phys, int(v)))
+        if cores:
+            return len(cores)
+    except (OSError, ValueError, AttributeError):
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
 def cpu_baseline(cfg, seconds_budget=20.0):
     """The CPU oracle (oracle/aecf_oracle.py, a port of the reference's arithmetic) timed on this box's host
-    cores on a bounded sample of the same workload: fp32, forward + explicit backward."""
+    cores on a bounded sample of the same workload: forward (+ train-mode masking + entropy loss) + explicit backward,
+    float32 and bfloat16.  torch's intra-op pool is set to the thread count that measures fastest among {physical cores,
+    32, 16, 8} (a 8192-row sample does not feed 64+ threads: the reference itself ran 24 k samples/s on 8 threads,
+    BASELINE.md section 2); `cores` = physical cores available, `threads` = the pool size used."""
     from oracle import aecf_oracle as O
     B, M, E, H, dtype, p = cfg
     n = min(B, 8192)
@@ -169,44 +203,48 @@ def cpu_baseline(cfg, seconds_budget=20.0):
     dy = torch.randn(n, 1, E, generator=g)
     U = torch.rand(n, 1, M, generator=g)
 
-    def one():
-        qe = q.expand(n, -1, -1)
-        f = O.mha_forward(qe, x, x, w_in, b_in, w_out, b_out, H)
-        m = O.curriculum_mask_train(f["wbar"], U, p)
-        O.entropy_loss(m["entropy"], M)
-        O.mha_backward(qe, x, x, w_in, b_in, w_out, H, f, dy, None)
+    def make(dt):
+        xs, qs, wi, bi, wo, bo, dys = (t_.to(dt) for t_ in (x, q, w_in, b_in, w_out, b_out, dy))
 
-    one()
-    best, reps, t_all = 1e30, 0, time.perf_counter()
-    while reps < 3 or (time.perf_counter() - t_all < seconds_budget and reps < 20):
-        t0 = time.perf_counter()
-        one()
-        best = min(best, time.perf_counter() - t0)
-        reps += 1
-    out = dict(value=n / best, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-               sample=f"{n} samples of the same [B,M={M},d={E}] workload, fp32, fwd+bwd, best of {reps}")
-    # bf16 leg (what torch's CPU bf16 kernels make of the same arithmetic): a few repetitions, bounded
-    try:
-        bf = torch.bfloat16
-        xb, qb, wib, bib, wob, bob, dyb = (t_.to(bf) for t_ in (x, q, w_in, b_in, w_out, b_out, dy))
+        def one():
+            qe = qs.expand(n, -1, -1)
+            f = O.mha_forward(qe, xs, xs, wi, bi, wo, bo, H)
+            m = O.curriculum_mask_train(f["wbar"].float(), U, p)
+            O.entropy_loss(m["entropy"], M)
+            O.mha_backward(qe, xs, xs, wi, bi, wo, H, f, dys, None)
+        return one
 
-        def one_bf16():
-            qe = qb.expand(n, -1, -1)
-            f = O.mha_forward(qe, xb, xb, wib, bib, wob, bob, H)
-            O.mha_backward(qe, xb, xb, wib, bib, wob, H, f, dyb, None)
-
-        one_bf16()
-        best_b, t_all = 1e30, time.perf_counter()
-        for _ in range(5):
+    def best_of(fn, budget, max_reps):
+        fn()
+        best, reps, t_all = 1e30, 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t_all < budget and reps < max_reps):
             t0 = time.perf_counter()
-            one_bf16()
-            best_b = min(best_b, time.perf_counter() - t0)
-            if time.perf_counter() - t_all > 8.0:
-                break
+            fn()
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+        return best, reps
+
+    cores = physical_cores()
+    saved = torch.get_num_threads()
+    one32 = make(torch.float32)
+    trial = {}
+    for nt in sorted({cores, 32, 16, 8}):
+        if nt <= cores:
+            torch.set_num_threads(nt)
+            trial[nt] = best_of(one32, 0.5, 3)[0]
+    threads = min(trial, key=trial.get)
+    torch.set_num_threads(threads)
+    best, reps = best_of(one32, seconds_budget * 0.5, 20)
+    out = dict(value=n / best, unit="samples/s", cores=cores, threads=threads, logical_cpus=os.cpu_count(), kind="port",
+               sample=f"{n} samples of the same [B,M={M},d={E}] workload, fp32, fwd (+ masking, entropy loss) + bwd, best of {reps}; "
+                      f"thread sweep {({k: round(n / v) for k, v in trial.items()})} samples/s")
+    try:      # bf16 leg (what torch's CPU bf16 kernels make of the same arithmetic), same step
+        best_b, _ = best_of(make(torch.bfloat16), seconds_budget * 0.3, 5)
         out["value_bf16"] = n / best_b
     except Exception as e:                      # a CPU without usable bf16 kernels: the fp32 leg stands alone
         out["value_bf16"] = None
         out["bf16_note"] = str(e)[:80]
+    torch.set_num_threads(saved)
     return out
 
 
@@ -248,6 +286,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = B per GPU fixed (default), strong = the config's B is the GLOBAL batch, sharded")
+    ap.add_argument("--contrastive", action="store_true",
+                    help="configs[2]: add the symmetric InfoNCE against 65536 gathered keys (+ entropy loss) to the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one gradient all-reduce after the backward")
     args = ap.parse_args()
@@ -288,10 +328,50 @@ def main():
     ugen = torch.Generator(device=device).manual_seed(1234) if world > 1 else None
     overlap = dp.GradOverlap() if (world > 1 and not args.no_overlap) else None
 
+    # --contrastive (configs[2]): the paired view.  zb_local = this rank's rows of the other view (resident, as the output of a
+    # second tower would be); N = 1: the 65536 gathered unit-norm keys are resident too (rank 3 of 8: offset 3 x 8192) and the
+    # local rows are written into their slots each step; N > 1: dp.all_gather_rows gathers them over RCCL each step.
+    nce = None
+    if args.contrastive:
+        if args.config != "c3":
+            sys.exit("--contrastive is defined for --config c3 (BASELINE configs[2])")
+        from aecf_amd import losses
+        gk = torch.Generator(device=device).manual_seed(77 + rank)
+        zb_local = (0.8 * x.detach()[:, 0].float() + 0.6 * torch.randn(B, E, device=device, generator=gk)).to(dtype)
+        if world == 1:
+            keys = losses.l2_normalize(torch.randn(NCE_KEYS, E, device=device, generator=gk).to(dtype)).detach()
+            nce = dict(offset=3 * B, keys=keys, cols=NCE_KEYS)
+        else:
+            nce = dict(offset=lo, keys=None, cols=B_global)
+        nce["zb"] = zb_local
+
+    def contrastive_step(u):
+        """pool forward -> fused rows z; symmetric InfoNCE of z against every rank's rows of the paired view + entropy
+        regulariser (one operator); backward through the loss and the pool (+ the gradient all-reduce when N > 1)."""
+        out, info = pool(query.expand(B, -1, -1), x, return_info=True, uniforms=u)
+        nb = losses.l2_normalize(nce["zb"])
+        if world == 1:
+            nb_all = nce["keys"]
+            nb_all[nce["offset"]:nce["offset"] + B] = nb            # the gather's local slot
+        else:
+            nb_all = dp.all_gather_rows(nb)
+        loss = losses.gathered_contrastive_entropy_loss(out.squeeze(1), nb_all, nce["offset"], pool.curriculum_masking,
+                                                        info["entropy"], temperature=NCE_TEMPERATURE)
+        x.grad = None
+        for prm in params:
+            prm.grad = None
+        loss.backward()
+        if world > 1:
+            from aecf_amd.dp import all_reduce_grads
+            all_reduce_grads(params)
+        return out, loss
+
     def one_step():
         u = None
         if ugen is not None:
             u = torch.rand(B_global, 1, M, device=device, dtype=torch.float32, generator=ugen)[lo:lo + B]
+        if nce is not None:
+            return contrastive_step(u)
         return step(pool, query, x, dy, params, world > 1, u, overlap)
 
     def barrier():
@@ -300,19 +380,68 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # per-stage durations (HIP events the library records on its launch stream), measured live over STAGE_PASS_STEPS extra
-    # steps BEFORE the warmup and the timed region, per-stage median.  (Side effect, stated in the line as "stage_pass": a
-    # fresh process needs ~15 steps / ~10 ms before its step time settles -- tools/step_trend.py: 0.83, 0.71, 0.68 ... 0.615 ms
-    # -- and with this pass first the W warmup steps no longer carry that.)
+    # A fresh process needs ~25 steps (~15 ms) before its step time settles (tools/step_trend.py: 0.66, 0.65 ... 0.59 ms; 300 ms
+    # of unrelated device work beforehand does not shorten it): SETTLE_STEPS untimed steps come first and are reported in the line
+    # ("settle_steps", "effective_warmup"), then the W warm-up steps, then exactly K timed steps.
+    for _ in range(SETTLE_STEPS + args.warmup):
+        one_step()
+    barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (same stream)
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        one_step()
+        marks[i + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2]
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
+
+    # per-stage durations (HIP events the library records on its launch stream), measured live over STAGE_PASS_STEPS extra steps
+    # AFTER the timed region (device warm: the stage times are those of steps like the timed ones), per-stage median
     roofline = None
     stages = None
-    st = StageTimer()                    # (every rank runs the pass -- the same start-up for all -- rank 0 reports it)
+    st = StageTimer()                    # (every rank runs the pass -- the same tail for all -- rank 0 reports it)
     for _ in range(STAGE_PASS_STEPS):
         st.arm()
         step(pool, query, x, dy, params, False, None)
         st.disarm()
         torch.cuda.synchronize()
         st.collect()
+    nce_ms = None
+    if nce is not None:                  # the two C-ABI calls of the loss side, HIP events on the launch stream
+        from aecf_amd import _lib
+        from aecf_amd.layer import _ptr, _stream
+        lib = _lib.load()
+        rows, cols = B, nce["cols"]
+        na = losses.l2_normalize(x.detach()[:, 0].contiguous())
+        nb_all = nce["keys"] if world == 1 else losses.l2_normalize(torch.randn(cols, E, device=device).to(dtype))
+        f32 = dict(dtype=torch.float32, device=device)
+        ws_bytes = lib.aecf_nce_sym_workspace_bytes(rows, cols, E)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        cs, lr = torch.empty(cols, **f32), torch.empty(rows, **f32)
+        da, db = torch.empty(rows, E, **f32), torch.empty(cols, E, **f32)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t1, t2 = [], []
+        for _ in range(10):
+            ev[0].record()
+            _lib.check(lib.aecf_nce_sym_pass1(rows, cols, E, NCE_TEMPERATURE, _ptr(na), _ptr(nb_all), _ptr(ws), ws_bytes, _ptr(cs),
+                                              _stream()), "aecf_nce_sym_pass1")
+            ev[1].record()
+            _lib.check(lib.aecf_nce_sym_pass2(rows, cols, nce["offset"], E, NCE_TEMPERATURE, 0.5 / cols, _ptr(na), _ptr(nb_all),
+                                              _ptr(cs), _ptr(ws), ws_bytes, _ptr(lr), _ptr(da), _ptr(db), 0, 2, 0.0, None, 1.0,
+                                              None, None, _stream()), "aecf_nce_sym_pass2")
+            ev[2].record()
+            torch.cuda.synchronize()
+            t1.append(ev[0].elapsed_time(ev[1]))
+            t2.append(ev[1].elapsed_time(ev[2]))
+        nce_ms = {"nce.pass1 (logits GEMM + exp + sums)": sorted(t1)[5], "nce.pass2 (weights, da, db)": sorted(t2)[5]}
+        del ws, da, db
     if rank == 0:
         stages = st.median_ms()
         model = stage_model(cfg)
@@ -336,52 +465,55 @@ def main():
         else:
             roofline = dict(bound="mfma", achieved=tfl, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=tfl / MFMA_PEAK_TFLOPS, traffic=traffic, kernel=dom, kernel_ms=stages[dom], **both)
-
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (same stream)
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        one_step()
-        marks[i + 1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    median_ms = per_step[len(per_step) // 2]
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
+        if nce_ms is not None:
+            # the step's dominant kernel is the logits GEMM of pass 1: 2 rows cols d MFMA flops; its algorithmic bytes are the
+            # two embedding matrices read + E written (rows x cols bf16)
+            t1 = nce_ms["nce.pass1 (logits GEMM + exp + sums)"] * 1e-3
+            fl = 2.0 * B * nce["cols"] * E
+            by = 2.0 * (B * E + nce["cols"] * E + B * nce["cols"])
+            roofline = dict(bound="mfma", achieved=fl / t1 / 1e12, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=fl / t1 / 1e12 / MFMA_PEAK_TFLOPS, traffic=None,
+                            kernel="nce_gemm_kernel<logits> (aecf_nce_sym_pass1; + the 30 us sum kernel)", kernel_ms=t1 * 1e3,
+                            hbm_frac=by / t1 / 1e9 / HBM_PEAK_GBS, mfma_frac=fl / t1 / 1e12 / MFMA_PEAK_TFLOPS,
+                            alg_GBps=by / t1 / 1e9, executed_TFLOPs=fl / t1 / 1e12,
+                            loss_side_executed_TFLOPs=6.0 * B * nce["cols"] * E / (sum(nce_ms.values()) * 1e-3) / 1e12)
+            stages = dict(stages, **nce_ms)
 
     if rank == 0:
         sec = elapsed / args.steps
         s_bytes = 2 if dtype == torch.bfloat16 else 4
         path_bytes = s_bytes * E * (3 * M + 2)                    # fwd+bwd algorithmic bytes per sample
         path_flops = sum(v["flops"] for v in stage_model(cfg).values())     # MFMA flops this decomposition executes
+        if nce is not None:
+            path_flops += 6.0 * nce["cols"] * E                   # per local sample: logits + the two gradient products
+            path_bytes += s_bytes * (2 * E + 2 * nce["cols"]) + 4 * E        # z, dz, the E row written + re-read twice ... per sample
         cb = None
         if not (args.no_cpu_baseline or world > 1):
             cb = cpu_baseline(cfg)
             cb["cpu_model"] = cpu_model()
+        workload = f"{args.config}: [B={B} per GPU, M={M}, d={E}, {H} heads] mask_prob={p} train-mode curriculum masking, fwd+bwd"
+        coll = None if world == 1 else (
+            f"{backend}: all-reduce of {4 * E * E + 5 * E} grads/step" +
+            (" (one call, behind the dx kernel)" if overlap is not None and nce is None else " (one call, after the backward)"))
+        if nce is not None:
+            workload += (f" + symmetric InfoNCE of the fused rows against {nce['cols']} gathered rows of the paired view "
+                         f"(T={NCE_TEMPERATURE}) + entropy loss, one logits block for both directions")
+            if world > 1:
+                coll += f"; all-gather of [{B},{E}] rows + reduce-scatter of their gradient; all-reduce of {nce['cols']} column sums"
         line = {
             "metric": "fused samples/sec (fwd+bwd)", "value": B_global / sec, "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS,
+            "effective_warmup": SETTLE_STEPS + args.warmup, "ms_per_step": sec * 1e3,
             "ms_per_step_median": median_ms,
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: [B={B} per GPU, M={M}, d={E}, {H} heads] mask_prob={p} "
-                                   "train-mode curriculum masking, fwd+bwd", "global_batch": B_global,
-                       "parallelism": f"dp{world}", "world_size": world,
-                       "collectives": None if world == 1 else (
-                           f"{backend}: all-reduce of {4 * E * E + 5 * E} grads/step" +
-                           (" (one call, behind the dx kernel)" if overlap is not None else " (one call, after the backward)"))},
+            "config": {"workload": workload, "global_batch": B_global,
+                       "parallelism": f"dp{world}", "world_size": world, "collectives": coll},
             "roofline": roofline,
             "path_hbm_frac": path_bytes * B / sec / 1e9 / HBM_PEAK_GBS,
             "path_mfma_frac": path_flops * B / sec / 1e12 / MFMA_PEAK_TFLOPS,
             "stage_ms": stages,
-            "stage_pass": {"steps": STAGE_PASS_STEPS, "when": "before warmup", "stat": "median"},
+            "stage_pass": {"steps": STAGE_PASS_STEPS, "when": "after the timed region", "stat": "median"},
             "cpu_baseline": cb,
         }
         print(json.dumps(line), flush=True)

@@ -25,7 +25,7 @@ def main():
     cs = torch.empty(cols, **f32)
     _lib.check(lib.aecf_nce_sym_pass1(rows, cols, d, T, _ptr(a), _ptr(b), _ptr(ws), ws_bytes, _ptr(cs), _stream()), "p1")
     torch.cuda.synchronize()
-    E = ws[:Rp * (Cp + 64) * 2].view(torch.bfloat16).view(Rp, Cp + 64)[:, :Cp].clone()
+    E = ws[:Rp * Cp * 2].view(torch.bfloat16).view(Rp // 256, Cp // 64, 256, 64).permute(0, 2, 1, 3).reshape(Rp, Cp).clone()
     S = a.float() @ b.float().T
     Eref = torch.exp((S - 1.0) / T)
     print("E valid block rel err", rel(E[:rows, :cols].float(), Eref), " padding max", float(E[rows:].abs().max()) if Rp > rows else 0.0,
@@ -37,7 +37,7 @@ def main():
     _lib.check(lib.aecf_nce_sym_pass2(rows, cols, off, d, T, coef, _ptr(a), _ptr(b), _ptr(cs), _ptr(ws), ws_bytes, _ptr(lr), _ptr(da),
                                       _ptr(db), 0, 2, 0.0, None, 1.0, None, None, _stream()), "p2")
     torch.cuda.synchronize()
-    W = ws[:Rp * (Cp + 64) * 2].view(torch.bfloat16).view(Rp, Cp + 64)[:, :Cp].clone().float()
+    W = ws[:Rp * Cp * 2].view(torch.bfloat16).view(Rp // 256, Cp // 64, 256, 64).permute(0, 2, 1, 3).reshape(Rp, Cp).clone().float()
     l, c = Eref.sum(1), Eref.sum(0)
     Wref = Eref * (1 / l[:, None] + 1 / c[None, :])
     idx = torch.arange(rows, device=dev)
