@@ -313,14 +313,29 @@ void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat
         modality_frontend_kernel<F32><<<grid, block, 0, s>>>(rows, dim, (const float*)feat, drop, (float*)out, present);
 }
 
-// small n: ONE block does both stages (a second launch costs more than the work)
+// n up to 256 k rows: ONE block does both stages (a second launch and the gap in front of it cost more than the work).
+// 16-byte loads, all of a thread's loads independent: 1024 threads x 16 bytes cover 8192 bf16 / 4096 float32 entropies per
+// round -- the headline batch (65536 rows) is 8 rounds.
 template <typename T>
 __global__ __launch_bounds__(1024) void entropy_loss_single_kernel(int64_t n, float target, const typename Tr<T>::elem* __restrict__ e,
                                                                    float scale_grad, float inv_n, float* __restrict__ d_e,
                                                                    typename Tr<T>::elem* __restrict__ loss) {
+    constexpr int V = 16 / Tr<T>::BYTES;                         // elements per 16-byte load
     __shared__ float red[16];
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const bool vec = (reinterpret_cast<uintptr_t>(e) & 15) == 0;
+    const int64_t nv = vec ? n / V : 0;
+    for (int64_t c = threadIdx.x; c < nv; c += 1024) {
+        float v[V];
+        Tr<T>::unpack(*reinterpret_cast<const typename Tr<T>::frag*>(e + c * V), v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float d = nan_to_num_ref(v[k]) - target;
+            acc += d * d;
+            if (d_e) d_e[c * V + k] = isfinite(v[k]) ? scale_grad * d : 0.f;
+        }
+    }
+    for (int64_t i = nv * V + threadIdx.x; i < n; i += 1024) {
         const float raw = Tr<T>::to_f32(e[i]);
         const float d = nan_to_num_ref(raw) - target;
         acc += d * d;
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(1024) void entropy_loss_single_kernel(int64_t n, fl
 
 void launch_entropy_loss(int dtype, int64_t n, float target, const void* entropy, float upstream, void* loss,
                          float* d_entropy, float* partial, hipStream_t s) {
-    if (n <= 8192) {       // (one block walks n/1024 dependent rounds: beyond a few thousand rows two launches win)
+    if (n <= 262144) {
         const float inv = 1.0f / (float)n;
         if (dtype == 0)
             entropy_loss_single_kernel<BF16><<<dim3(1), dim3(1024), 0, s>>>(n, target, (const unsigned short*)entropy,

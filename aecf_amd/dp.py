@@ -173,16 +173,29 @@ def flat_grad_alias(params: Iterable[torch.nn.Parameter]) -> Optional[torch.Tens
     return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(st, spans[0][0], (off - spans[0][0],))
 
 
-def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = True):
+def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = True, fp32: bool = False):
     """One collective for the gradients of ``params``: in place over their shared allocation when they alias one
     (see flat_grad_alias), else through a temporary flat copy.  Averages inside the collective (ReduceOp.AVG) when
     probe_avg_support found the backend takes it, else divides and sums.  The average is unweighted: with uneven
-    shards scale the local loss by shard_loss_scale."""
+    shards scale the local loss by shard_loss_scale.  ``fp32=True``: reduced-precision gradients (bf16 parameters) travel and
+    are summed as float32 and are rounded ONCE after the collective (a ring sum in bf16 rounds at every hop; each rank's own
+    rounding of its float32 batch sums to its bf16 ``p.grad`` has already happened and stays)."""
     params = [p for p in params if p.requires_grad and p.grad is not None]
     _, world = world_info(group)
     if world == 1 or not params:
         return
     flat = flat_grad_alias(params)
+    if fp32 and (flat is None or flat.dtype != torch.float32):
+        wide = torch.cat([p.grad.reshape(-1).float() for p in params])
+        dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            wide.div_(world)
+        off = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(wide[off:off + n].view_as(p.grad))
+            off += n
+        return
     copied = flat is None
     if copied:
         flat = torch.cat([p.grad.reshape(-1).to(params[0].grad.dtype) for p in params])
@@ -201,31 +214,40 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
 
 
 class GradOverlap:
-    """Runs the all-reduce of the fusion layer's parameter gradients BEHIND the input-gradient kernel of its backward.
+    """EXPERIMENTAL (never run over RCCL on real multi-GPU hardware by this build: only the gloo rehearsal on one GPU).
+    Runs the all-reduce of the fusion layer's parameter gradients BEHIND the input-gradient kernel of its backward.
 
     With this object installed (as ``layer._param_grads_hook``) the backward computes dx last and the library announces
     the moment the five parameter gradients are final with a HIP event (aecf_pool_bwd_args.param_grads_event); a side
     stream waits for that event and issues ONE collective there, in place on the gradient allocation, while the dx
-    kernel runs on the caller's stream.  ``finish`` makes the current stream wait for it (and reduces, the plain way,
-    any parameters the layer's allocation does not cover).  Use:
+    kernel runs on the caller's stream.  ``finish`` makes the current stream wait for every collective issued that way
+    (one per fused backward: two pool layers, or two backward calls of an accumulation step, give two) and reduces, the
+    plain way, any parameters they did not cover.  Use:
 
-        overlap = dp.GradOverlap()
+        overlap = dp.GradOverlap(params=params)
         with overlap:                 # installs / removes the hook
             loss.backward()
             overlap.finish(params)    # instead of dp.all_reduce_grads(params)
 
+    The in-place collective is only sound when autograd KEEPS the backward's tensors as ``p.grad`` (it then never reads them
+    on the main stream while the side stream mutates them).  Two cases break that and are refused: gradients that arrive as
+    cast copies (parameter dtype != gradient dtype: the layer does not call the hook) and parameters that already hold a
+    gradient (accumulation adds into it on the main stream): pass ``params`` and the hook is not installed for a backward
+    that starts with any ``p.grad`` set -- ``finish`` then falls back to the plain all-reduce.
+
     The collective is ~2 MB and latency-bound on xGMI; dx is ~13 % of the step, which is what it can hide behind."""
 
-    def __init__(self, group=None, average: bool = True):
+    def __init__(self, group=None, average: bool = True, params: Optional[Iterable[torch.nn.Parameter]] = None):
         self.group, self.average = group, average
+        self.params = None if params is None else list(params)
         self.stream = None
-        self.flat = None
-        self.work = None
+        self.pending = []                                   # (flat, work) of every collective issued since the last finish
 
     def __enter__(self):
         from . import layer
         _, world = world_info(self.group)
-        if world > 1:
+        accumulating = self.params is not None and any(p.grad is not None for p in self.params)
+        if world > 1 and not accumulating:
             layer._param_grads_hook = self
         return self
 
@@ -247,25 +269,26 @@ class GradOverlap:
             self.stream = torch.cuda.Stream(device=flat.device)
         self.stream.wait_event(event)                       # the gradients are final once the library's event has fired
         with torch.cuda.stream(self.stream):
-            self.work = self._reduce(flat, async_op=True)
+            work = self._reduce(flat, async_op=True)
         flat.record_stream(self.stream)
-        self.flat = flat
+        self.pending.append((flat, work))
 
     def finish(self, params: Iterable[torch.nn.Parameter]) -> None:
-        """Wait for the collective issued behind dx; all-reduce whatever it did not cover."""
+        """Wait for the collectives issued behind dx; all-reduce whatever they did not cover."""
         params = [p for p in params if p.requires_grad and p.grad is not None]
         _, world = world_info(self.group)
+        pending, self.pending = self.pending, []
         if world == 1 or not params:
             return
-        if self.work is None:                               # the hook never fired (no fused backward ran): plain path
+        if not pending:                                     # the hook never fired (no fused backward ran): plain path
             all_reduce_grads(params, self.group, self.average)
             return
-        self.work.wait()
+        spans = []
+        for flat, work in pending:
+            work.wait()
+            spans.append((flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
         torch.cuda.current_stream().wait_stream(self.stream)
-        lo = self.flat.data_ptr()
-        hi = lo + self.flat.numel() * self.flat.element_size()
-        rest = [p for p in params if not (lo <= p.grad.data_ptr() < hi)]
-        self.flat = self.work = None
+        rest = [p for p in params if not any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]
         if rest:
             all_reduce_grads(rest, self.group, self.average)
 

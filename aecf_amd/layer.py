@@ -200,6 +200,8 @@ class _PoolFunction(torch.autograd.Function):
         ws_bytes = ctx.bwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         hook, early = _param_grads_hook, None
+        if hook is not None and any(p is not None and p != gdt for p in ctx.param_dtypes):
+            hook = None        # the gradients handed to autograd would be cast COPIES of `flat`: nothing to reduce in place
         if hook is not None:
             early = torch.cuda.Event()
             early.record()                         # (creates the underlying hipEvent; the library records it again later)
@@ -558,11 +560,20 @@ class MultimodalAttentionPool(nn.Module):
                                                bias=bias, batch_first=batch_first, device=device, dtype=dtype)
         self._cast_cache: Dict[str, Any] = {}
 
+    def invalidate_cast_cache(self) -> None:
+        """Forget the activation-dtype copies of the parameters (see _activation_dtype_params).  Call it after changing a
+        parameter through ``p.data`` (``p.data.copy_(...)``, EMA / weight swapping, optimizers that step on ``.data``) while
+        the module is in eval mode under ``torch.no_grad()``: such writes do not move the parameter's version counter."""
+        self._cast_cache.clear()
+
     def _activation_dtype_params(self, dt: torch.dtype):
         """Master weights kept in another dtype than the activations (float32 parameters, bf16 data): the kernels want
-        them in the activation dtype.  The copies are remade only when a parameter has changed (its autograd version or
-        storage moved), not on every forward -- 4E^2 elements and 3-4 cast launches per call otherwise."""
+        them in the activation dtype.  Inference (eval mode, or no gradient recording) reuses the copies while the
+        parameters' version counters and storage stand still; whenever the module trains they are remade on every forward:
+        an optimizer that steps through ``p.data`` (apex / DeepSpeed style, EMA, clipping on ``.data``) leaves the version
+        counter alone, and stale weights would go unnoticed.  ``invalidate_cast_cache()`` covers ``.data`` writes in eval."""
         a = self.attention
+        reuse = not (self.training and torch.is_grad_enabled())
         out = []
         for name, p in (("w_in", a.in_proj_weight), ("b_in", a.in_proj_bias), ("w_out", a.out_proj.weight),
                         ("b_out", a.out_proj.bias)):
@@ -570,7 +581,7 @@ class MultimodalAttentionPool(nn.Module):
                 out.append(None)
                 continue
             key = (p._version, p.data_ptr(), p.device, dt)
-            hit = self._cast_cache.get(name)
+            hit = self._cast_cache.get(name) if reuse else None
             if hit is None or hit[0] != key:
                 hit = (key, p.detach().to(dt).contiguous())
                 self._cast_cache[name] = hit

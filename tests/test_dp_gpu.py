@@ -83,13 +83,59 @@ def _worker(rank, world, port, backend, dtype, q):
         # the same step with the out-projection gradients' all-reduce started behind the rest of the backward
         for p in params:
             p.grad = None
-        overlap = dp.GradOverlap()
+        overlap = dp.GradOverlap(params=params)
         with overlap:
             _run_shard(query, pool, x[lo:hi], dy[lo:hi], u, dev, float(world))
             overlap.finish(params)
         torch.cuda.synchronize()
         for a_, b_ in zip(plain, [p.grad for p in params]):
             assert torch.equal(a_, b_), "overlapped all-reduce differs from the single collective"
+        # two fused backward calls inside one overlapped region (two pool applications feeding one loss): two collectives
+        # are in flight, finish() waits for both; the gradients are the sum of the two backwards' reduced gradients
+        for p in params:
+            p.grad = None
+        mid = (lo + hi) // 2
+        overlap = dp.GradOverlap()
+        with overlap:
+            xa, xb = x[lo:mid].to(dev).requires_grad_(True), x[mid:hi].to(dev).requires_grad_(True)
+            oa, _ = pool(query.expand(mid - lo, -1, -1), xa, return_info=True, uniforms=u[:mid - lo])
+            ob, _ = pool(query.expand(hi - mid, -1, -1), xb, return_info=True, uniforms=u[mid - lo:])
+            loss2 = ((oa.float() * dy[lo:mid].to(dev).float()).sum() + (ob.float() * dy[mid:hi].to(dev).float()).sum()) / B * world
+            loss2.backward()
+            assert len(overlap.pending) == 2
+            overlap.finish(params)
+        torch.cuda.synchronize()
+        two = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        loss2 = None
+        xa, xb = x[lo:mid].to(dev).requires_grad_(True), x[mid:hi].to(dev).requires_grad_(True)
+        oa, _ = pool(query.expand(mid - lo, -1, -1), xa, return_info=True, uniforms=u[:mid - lo])
+        ob, _ = pool(query.expand(hi - mid, -1, -1), xb, return_info=True, uniforms=u[mid - lo:])
+        (((oa.float() * dy[lo:mid].to(dev).float()).sum() + (ob.float() * dy[mid:hi].to(dev).float()).sum()) / B * world).backward()
+        dp.all_reduce_grads(params)
+        torch.cuda.synchronize()
+        tol2 = 1e-5 if dtype == torch.float32 else 2e-2       # (sum of two reduced gradients vs reduced sum: one more rounding)
+        for a_, p in zip(two, params):
+            err = (a_.float() - p.grad.float()).abs().max().item() / max(p.grad.float().abs().max().item(), 1e-12)
+            assert err < tol2, err
+        # a backward that starts with gradients already set (accumulation): the hook is not installed, finish() reduces plainly
+        overlap = dp.GradOverlap(params=params)
+        with overlap:
+            from aecf_amd import layer as _layer
+            assert _layer._param_grads_hook is None
+        # float32 transport of reduced-precision gradients: equal to the plain collective up to one rounding
+        if dtype == torch.bfloat16:
+            for p in params:
+                p.grad = None
+            _run_shard(query, pool, x[lo:hi], dy[lo:hi], u, dev, float(world))
+            dp.all_reduce_grads(params, fp32=True)
+            torch.cuda.synchronize()
+            for a_, p in zip(plain, params):
+                err = (a_.float() - p.grad.float()).abs().max().item() / max(a_.float().abs().max().item(), 1e-12)
+                assert err < 1e-2, err
+        for p, g in zip(params, plain):
+            p.grad = g
         q.put((rank, lo, hi, out.float().cpu().numpy(), masked.float().cpu().numpy(), dx.float().cpu().numpy(),
                [p.grad.float().cpu().numpy() for p in params], [p.detach().float().cpu().numpy() for p in params]))
     finally:
@@ -170,3 +216,62 @@ def test_trainer_two_ranks_learns_and_toggles():
     assert len(rows) == 6 and [x["curriculum"] for x in rows] == [False] * 4 + [True] * 2
     assert rows[3]["train_loss"] < 0.8 * rows[0]["train_loss"]
     assert rows[-1]["val_map"] > 0.4 and rows[-1]["gate_entropy"] > 0.0
+
+
+def _nce_worker(rank, world, port, backend, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from aecf_amd import dp, losses
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, d = 640, 256
+        g = torch.Generator().manual_seed(4)
+        za = torch.randn(n, d, generator=g).to(torch.bfloat16)
+        zb = (0.7 * za.float() + 0.6 * torch.randn(n, d, generator=g)).to(torch.bfloat16)
+        lo, hi = dp.shard_bounds(n, rank, world)
+        a = za[lo:hi].to(dev).requires_grad_(True)
+        b = zb[lo:hi].to(dev).requires_grad_(True)
+        loss = losses.info_nce(a, b, temperature=0.07)           # symmetric tile-GEMM form: all-gather of b, column-sum all-reduce
+        loss.backward()
+        torch.cuda.synchronize()
+        # gradients follow the data-parallel convention (averaged over ranks later): undo the factor `world`
+        q.put((rank, lo, hi, float(loss), (a.grad.float() / world).cpu().numpy(), (b.grad.float() / world).cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_info_nce_two_ranks_equal_one_rank():
+    """Cross-batch negatives through dp.all_gather_rows + the column-sum all-reduce of the symmetric form: loss value and
+    the gradients of both views on two ranks equal the one-rank full batch."""
+    from aecf_amd import losses
+    world = 2
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nce_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    n, d = 640, 256
+    g = torch.Generator().manual_seed(4)
+    za = torch.randn(n, d, generator=g).to(torch.bfloat16)
+    zb = (0.7 * za.float() + 0.6 * torch.randn(n, d, generator=g)).to(torch.bfloat16)
+    a = za.to(dev).requires_grad_(True)
+    b = zb.to(dev).requires_grad_(True)
+    want = losses.info_nce(a, b, temperature=0.07)
+    want.backward()
+    for rank, lo, hi, loss, ga, gb in res:
+        assert abs(loss - float(want)) < 2e-3 * abs(float(want))          # every rank reports the global loss
+        ra, rb = a.grad[lo:hi].float().cpu(), b.grad[lo:hi].float().cpu()
+        assert (torch.from_numpy(ga) - ra).abs().max() / ra.abs().max() < 2e-2
+        assert (torch.from_numpy(gb) - rb).abs().max() / rb.abs().max() < 2e-2

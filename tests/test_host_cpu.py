@@ -175,3 +175,27 @@ def test_uniforms_argument_is_public_and_validated():
     assert names[:8] == ["self", "query", "key", "value", "key_padding_mask", "attn_mask", "return_info", "use_checkpoint"]
     with pytest.raises(ValueError):
         layer._draw_uniforms((4, 1, 3), torch.device("cpu"), torch.zeros(5))
+
+
+def test_cast_cache_follows_data_writes():
+    """Float32 master weights, bf16 activations: the activation-dtype copies of the parameters are remade on every forward
+    while the module trains (writes through ``p.data`` do not move the version counter), reused in inference, and
+    ``invalidate_cast_cache`` covers ``.data`` writes in eval mode."""
+    import torch
+    import aecf_amd
+    _, pool = aecf_amd.create_fusion_pool(64, 2, num_heads=2)
+    pool.train()
+    w0 = pool._activation_dtype_params(torch.bfloat16)[0].clone()
+    pool.attention.in_proj_weight.data.mul_(2.0)                  # what an optimizer stepping on .data does
+    w1 = pool._activation_dtype_params(torch.bfloat16)[0]
+    assert torch.equal(w1.float(), (w0.float() * 2.0))
+    pool.eval()
+    with torch.no_grad():
+        c0 = pool._activation_dtype_params(torch.bfloat16)[0]
+        assert pool._activation_dtype_params(torch.bfloat16)[0] is c0          # reused
+        pool.attention.in_proj_weight.mul_(0.5)                                # in-place op on the parameter: version moves
+        c1 = pool._activation_dtype_params(torch.bfloat16)[0]
+        assert c1 is not c0 and torch.equal(c1.float(), c0.float() * 0.5)
+        pool.attention.in_proj_weight.data.mul_(2.0)                           # invisible to the version counter ...
+        pool.invalidate_cast_cache()                                           # ... hence the explicit call
+        assert torch.equal(pool._activation_dtype_params(torch.bfloat16)[0].float(), c0.float())
