@@ -3,6 +3,8 @@
 // enqueues the kernels on the caller's stream (the pool forward / backward as one executable graph per call, see
 // run_as_graph).  No device allocation, no synchronisation, no exceptions.
 #include <math.h>
+#include <stdio.h>
+#include <string>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -17,9 +19,8 @@ using namespace aecf;
 namespace {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-int env_dx_reserve();          // AECF_DX_RESERVE_CUS (same place)
-bool env_no_ws();              // AECF_NO_WS / AECF_NO_GATE_FUSION / AECF_FUSED_FWD, read once per process (defined with the graph cache)
-bool env_no_gate_fusion();
+int env_dx_reserve();          // tokens of the one debug knob AECF_DEBUG, read once per process (defined with the graph cache;
+bool env_no_gate_fusion();     //  env_no_ws / env_no_wide_tn / env_no_slab are declared in aecf_kernels.h: other files ask too)
 bool env_fused_fwd();
 inline int esize(int dtype) { return dtype == AECF_BF16 ? 2 : 4; }
 
@@ -556,38 +557,65 @@ std::vector<GraphSighting> g_graph_seen;
 hipStream_t g_capture_stream[MAX_DEVICES] = {};
 uint64_t g_graph_clock = 0;
 
-// environment switches are read once per process (A/B timing and tests), never on the call path
+// ONE debug knob, read once per process (tests and A/B timing; never on the call path): AECF_DEBUG = comma-separated tokens
+//   graph=0 | graph=1   force HIP-graph replay of a call off / on (default: by call size, graphs_enabled below)
+//   no_ws               tiled round-1 kernels instead of the weight-stationary ones
+//   no_gate_fusion      scores / softmax as their own kernel instead of inside the value projection
+//   no_wide_tn          128-row tiles instead of the 1024-thread 256-row form of the pooled batch reduction
+//   no_slab             the two-barrier gated value projection instead of its column-slab form (d = 512)
+//   fused_fwd           the one-kernel forward north_star names (aecf_row_fwd.hip; measured slower: profiles/r03_c2_fusedfwd_*)
+//   dx_reserve=N        CUs the dx kernel leaves free when it runs beside a collective (default 16, 0..128)
 struct EnvSwitches {
-    int graph;          // AECF_GRAPH: -1 unset, 0 off, 1 on
-    bool no_ws;         // AECF_NO_WS: tiled kernels instead of the weight-stationary ones
-    int no_gate_fusion; // AECF_NO_GATE_FUSION
-    int dx_reserve;     // AECF_DX_RESERVE_CUS: CUs the dx kernel leaves free when it runs beside a collective (default 16)
-    int fused_fwd;      // AECF_FUSED_FWD=1: the one-kernel row-stationary forward (aecf_row_fwd.hip) instead of the
-                        // weight-stationary pair (measured slower at C2: DESIGN.md section 5)
+    int graph = -1;
+    bool no_ws = false, no_gate_fusion = false, no_wide_tn = false, no_slab = false, fused_fwd = false;
+    int dx_reserve = 16;
 };
 const EnvSwitches& env_switches() {
     static const EnvSwitches e = [] {
         EnvSwitches v;
-        v.graph = getenv("AECF_GRAPH") ? atoi(getenv("AECF_GRAPH")) : -1;
-        v.no_ws = getenv("AECF_NO_WS") != nullptr;
-        v.no_gate_fusion = getenv("AECF_NO_GATE_FUSION") ? atoi(getenv("AECF_NO_GATE_FUSION")) : 0;
-        v.fused_fwd = getenv("AECF_FUSED_FWD") ? atoi(getenv("AECF_FUSED_FWD")) : 0;
-        v.dx_reserve = getenv("AECF_DX_RESERVE_CUS") ? atoi(getenv("AECF_DX_RESERVE_CUS")) : 16;
-        if (v.dx_reserve < 0 || v.dx_reserve > 128) v.dx_reserve = 16;
+        const char* env = getenv("AECF_DEBUG");
+        if (!env) return v;
+        std::string all(env);
+        size_t pos = 0;
+        while (pos <= all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string tok = all.substr(pos, end - pos);
+            pos = end + 1;
+            if (tok == "graph=0") v.graph = 0;
+            else if (tok == "graph=1") v.graph = 1;
+            else if (tok == "no_ws") v.no_ws = true;
+            else if (tok == "no_gate_fusion") v.no_gate_fusion = true;
+            else if (tok == "no_wide_tn") v.no_wide_tn = true;
+            else if (tok == "no_slab") v.no_slab = true;
+            else if (tok == "fused_fwd") v.fused_fwd = true;
+            else if (tok.rfind("dx_reserve=", 0) == 0) {
+                const int n = atoi(tok.c_str() + 11);
+                if (n >= 0 && n <= 128) v.dx_reserve = n;
+            } else if (!tok.empty()) {
+                fprintf(stderr, "libaecf_hip: unknown AECF_DEBUG token '%s' (ignored)\n", tok.c_str());
+            }
+        }
         return v;
     }();
     return e;
 }
 
-bool env_no_ws() { return env_switches().no_ws; }
-bool env_no_gate_fusion() { return env_switches().no_gate_fusion != 0; }
-bool env_fused_fwd() { return env_switches().fused_fwd != 0; }
+bool env_no_gate_fusion() { return env_switches().no_gate_fusion; }
+bool env_fused_fwd() { return env_switches().fused_fwd; }
 int env_dx_reserve() { return env_switches().dx_reserve; }
+}  // namespace
+namespace aecf {
+bool env_no_ws() { return env_switches().no_ws; }
+bool env_no_wide_tn() { return env_switches().no_wide_tn; }
+bool env_no_slab() { return env_switches().no_slab; }
+}  // namespace aecf
+namespace {
 
 // Measured (C2, same box, 3 x A/B): the graph form halves the HOST cost of a step (0.39 -> 0.20 ms) but the GPU runs the
 // large kernels ~2 % slower under it (0.632 vs 0.619 ms), so it is used where the host is the bound: calls whose
 // activations are small (B*M*E up to 2^25 elements; the configs[2] shard at 8192 rows per GPU goes 0.37 -> 0.27 ms).
-// AECF_GRAPH=0 / 1 forces it off / on (A/B timing and tests; forced on also skips the sightings threshold).
+// AECF_DEBUG=graph=0 / graph=1 forces it off / on (A/B timing and tests; forced on also skips the sightings threshold).
 bool graphs_enabled(const aecf_pool_desc* d) {
     const int forced = env_switches().graph;
     if (forced >= 0) return forced != 0;

@@ -133,8 +133,7 @@ void launch_reduce_segments(const ReduceSegs& r, hipStream_t s) {
 
 void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s) {
     const int E = a.E;
-    static const int kc_env = getenv("AECF_FIN_KC") ? atoi(getenv("AECF_FIN_KC")) : 0;      // A/B timing only
-    int kc = kc_env > 0 ? kc_env : (E >= 1024 ? 4 : 1);           // keep >= 256 blocks
+    int kc = E >= 1024 ? 4 : 1;                                   // keep >= 256 blocks
     while ((E / 64) % kc != 0) --kc;
     if (dtype == 0) {
         fin_outer_kernel<BF16><<<dim3(E / 64 / kc, E / 16), dim3(256), 0, s>>>(a, kc);

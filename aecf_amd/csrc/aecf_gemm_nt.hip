@@ -166,8 +166,7 @@ static void launch_one(const GemmNtArgs& a, hipStream_t s) {
 
 void launch_gemm_nt(int dtype, const GemmNtArgs& a_in, hipStream_t s) {
     GemmNtArgs a = a_in;
-    static const int no_ws = getenv("AECF_NO_WS") ? atoi(getenv("AECF_NO_WS")) : 0;              // A/B timing only
-    if (dtype == 0 && !no_ws && gemm_ws_supported(a)) { launch_gemm_ws(a, s); return; }   // aecf_gemm_ws.hip
+    if (dtype == 0 && !env_no_ws() && gemm_ws_supported(a)) { launch_gemm_ws(a, s); return; }   // aecf_gemm_ws.hip
     if (a.pooled & 1) { launch_vproj(dtype, a, s); return; }     // per-modality accumulators (aecf_vproj.hip)
     if (dtype == 0) launch_one<BF16, 1, false>(a, s); else launch_one<F32, 1, false>(a, s);
 }

@@ -631,12 +631,8 @@ static int max_slots_256(int E, int hd) {
 
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s) {
     if (!a.pooled) { launch_one<1, false, 1>(a, s); return; }
-    // pooling on the matrix pipe (aecf_gemm_tn_pm.hip): measured slower, opt-in for A/B timing and its test
-    static const int use_pm = getenv("AECF_PM") ? atoi(getenv("AECF_PM")) : 0;
-    if (use_pm && gemm_tn_pm_supported(a)) { launch_gemm_tn_pm(a, s); return; }
     // 256-row tiles (1024 threads) when they tile E exactly with at most 4 head slots and M <= 3 (128-VGPR budget)
-    static const int no_wide = getenv("AECF_NO_WIDE_TN") ? atoi(getenv("AECF_NO_WIDE_TN")) : 0;      // A/B timing only
-    if (!no_wide && a.Ej <= 0 && a.E % 256 == 0 && max_slots_256(a.E, a.hd) <= 4 &&
+    if (!env_no_wide_tn() && a.Ej <= 0 && a.E % 256 == 0 && max_slots_256(a.E, a.hd) <= 4 &&
         (a.M <= 3 || (a.M == 4 && max_slots_256(a.E, a.hd) <= 2))) {
         const bool two = max_slots_256(a.E, a.hd) <= 2;
         switch (a.M) {

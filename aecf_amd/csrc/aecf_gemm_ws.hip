@@ -866,16 +866,9 @@ int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     rpb = (rpb + 15) / 16 * 16;
     const int64_t nchunk = (a.B + rpb - 1) / rpb;
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
-    static const int pkdot = getenv("AECF_DSU_PKDOT") ? atoi(getenv("AECF_DSU_PKDOT")) : 0;     // A/B: bf16-rounded P in the dot
-    if (pkdot) {
-        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, true>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
-    } else {
-        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
-    }
+    auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
     return (int)nchunk;
 }
 
@@ -1174,8 +1167,7 @@ void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
     if (GATE) smem += (size_t)8 * M_ * 256 * sizeof(float);
     if (MODE == WS_VPROJ && GATE && KT == 16 && M_ <= 3) {         // hot shape (K = 512): the column-slab form
-        static const int no_slab = getenv("AECF_NO_SLAB") ? atoi(getenv("AECF_NO_SLAB")) : 0;      // A/B timing only
-        if (!no_slab) { launch_vproj_slab<(M_ <= 3 ? M_ : 3)>(a, s); return; }
+        if (!env_no_slab()) { launch_vproj_slab<(M_ <= 3 ? M_ : 3)>(a, s); return; }
     }
     auto kern = gemm_ws_kernel<KT, MODE, M_, GATE, CT>;
     if (smem > 64 * 1024)
@@ -1288,8 +1280,7 @@ int launch_dsu_ws(const BwdGArgs& a, float* u_slab, hipStream_t s) {
 
 // dx through the weight-stationary engine (bf16); false = shape not taken (caller uses launch_bwd_g(dx = true))
 bool launch_dx_ws(const BwdGArgs& a, hipStream_t s) {
-    static const int no_ws = getenv("AECF_NO_WS") ? atoi(getenv("AECF_NO_WS")) : 0;
-    if (no_ws) return false;
+    if (env_no_ws()) return false;
     if (a.M < 1 || a.M > 4) return false;
     if (a.hd % 32 != 0 || a.E != a.H * a.hd || 16 * a.H * a.M > 1024) return false;
     switch (a.E) {

@@ -146,8 +146,6 @@ struct GemmTnArgs {
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b64_tr_b16 form (main product only)
-bool gemm_tn_pm_supported(const GemmTnArgs& a);                // pooled product with the pooling on the matrix pipe
-void launch_gemm_tn_pm(const GemmTnArgs& a, hipStream_t s);
 
 // dst[g][i] = sum_s src[g][s*n[g] + i] for each of N segments, one launch
 struct ReduceSegs {
@@ -158,6 +156,11 @@ struct ReduceSegs {
     int splits[N];
     int dst_bf16[N];      // 1: dst is bf16 (one rounding of the float32 sum)
 };
+// tokens of the debug knob AECF_DEBUG (aecf_capi.hip)
+bool env_no_ws();
+bool env_no_wide_tn();
+bool env_no_slab();
+
 void launch_reduce_segments(const ReduceSegs& r, hipStream_t s);
 
 // dW_k[j][k] = qs[j] u[h(j)][k];  dqp[j] = scale * sum_k W_k[j][k] u[h(j)][k]

@@ -23,9 +23,11 @@
  *  - thread-safe: any thread may call with any stream of the current device; calls that replay a graph are serialised
  *    by one mutex.
  *  Library-owned state (all host-side, bounded, process-lifetime):
- *    * environment switches read once per process: AECF_GRAPH (0/1 forces graph replay off/on), AECF_NO_WS,
- *      AECF_NO_GATE_FUSION, AECF_NO_WIDE_TN (A/B timing: route a shape through the fallback kernels), AECF_FUSED_FWD
- *      (=1: the one-kernel row-stationary forward instead of the weight-stationary kernel pair);
+ *    * ONE debug knob, read once per process: the environment variable AECF_DEBUG = comma-separated tokens -- graph=0 / graph=1
+ *      (force graph replay off / on), no_ws, no_gate_fusion, no_wide_tn, no_slab (route a shape through the kernels that serve the
+ *      shapes the fast ones do not take: what the parity tests of those kernels use), fused_fwd (the one-kernel forward
+ *      instead of the weight-stationary kernel pair), dx_reserve=N.  Unknown tokens are reported on stderr and ignored;
+ *      unset = production behaviour;
  *    * one non-blocking capture stream per device, created on first use;
  *    * a cache of at most 8 hipGraphExec_t, least-recently-used evicted (hipGraphExecDestroy), keyed on
  *      (forward/backward, device, B, M, E, H, dtype, mask mode, which optional pointers are set).  A shape is captured

@@ -22,17 +22,14 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import ROOT, g2_names, g3_names, load_json, load_npz, rel_err, t
+from tests.helpers import BF16_BOUNDS, ROOT, g2_names, g3_names, load_json, load_npz, rel_err, t
 
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-5
 BF16_TOL = 1e-3
 BF16_STORE_TOL = 1e-3 + 2.0 ** -8     # + one bf16 output rounding of the largest element
-# bf16-STORE path, per tensor: measured on MI355X (gpurun_out/parity_errors.jsonl, g2 bf16 fixtures and the headline
-# shape) + ~25 % margin.  y / dx / wbar carry one output rounding (2^-9 of the element); the parameter gradients are
-# float32 batch sums of products whose operands (do, pooled rows) were rounded to bf16 once, then rounded to bf16.
-BF16_BOUNDS = dict(y=4.0e-3, wbar=4.0e-3, dx=4.0e-3, dquery=5.0e-3, dw_in=5.2e-3, db_in=5.2e-3, dw_out=4.7e-3, db_out=3.7e-3)
+# (per-tensor bounds of the bf16-STORE path: tests/helpers.py BF16_BOUNDS)
 
 
 def _dev():
@@ -153,13 +150,16 @@ def test_bf16_within_reference_envelope(case):
         got, truth = _run_module(g, torch.bfloat16, kpm), {k: t(g[k]) for k in env}
     errs = {k: rel_err(got[k], truth[k]) for k in env}
     _record("g6:" + case, **errs)
-    # Per tensor: no worse than the reference's bf16 module, with 15 % slack -- both are max-norms of rounding noise over
-    # ~1e5 elements, and two implementations of equal precision differ by that much on a single draw (measured: 46 of
-    # the 48 (case, tensor) pairs are below the reference outright, most by 20-50 %; dw_in at E = 128 is 7-14 % above).
-    # Over the whole case (sum over the tensors): strictly no worse.
+    # Per tensor: no worse than the reference's own bf16 module (floor: one bf16 rounding of the output).  Measured (round 3,
+    # worst ratio to the envelope over the six cases): dx 0.72, wbar 0.74, dquery 0.75, db_out 0.77, y 0.78, dw_out 0.93 --
+    # asserted with NO slack; db_in 1.00 (both implementations land on the same single output rounding: a tie, asserted
+    # with 5 %); dw_in 1.10 at E = 128 (its float32 batch sum takes do = dy W_o rounded to bf16 where the reference's
+    # autograd keeps a float32 accumulator across the fused matmul: asserted with 15 %).  Over the whole case (sum over the
+    # tensors): strictly no worse.
     one_rounding = 2.0 ** -8
+    slack = dict(dw_in=1.15, db_in=1.05)
     for k, e in errs.items():
-        assert e <= 1.15 * max(env[k], one_rounding), (case, k, e, env[k])
+        assert e <= slack.get(k, 1.0) * max(env[k], one_rounding), (case, k, e, env[k])
     assert sum(errs.values()) <= sum(env.values()), (case, errs, env)
 
 

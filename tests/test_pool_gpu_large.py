@@ -88,10 +88,10 @@ def test_full_size_bf16(name):
     f = O.mha_forward(qe, xs, xs, c(a.in_proj_weight), c(a.in_proj_bias), c(a.out_proj.weight), c(a.out_proj.bias), H)
     b = O.mha_backward(qe, xs, xs, c(a.in_proj_weight), c(a.in_proj_bias), c(a.out_proj.weight), H, f,
                        dy[:chunk].float(), None)
-    tol = 1e-3 + 2.0 ** -8
-    assert rel_err(c(full["y"][:chunk]), f["y"]) < tol
-    assert rel_err(c(full["w"][:chunk]), f["wbar"]) < tol
-    assert rel_err(c(full["dx"][:chunk]), b["dkey"] + b["dvalue"]) < tol
+    from tests.helpers import BF16_BOUNDS
+    assert rel_err(c(full["y"][:chunk]), f["y"]) < BF16_BOUNDS["y"]
+    assert rel_err(c(full["w"][:chunk]), f["wbar"]) < BF16_BOUNDS["wbar"]
+    assert rel_err(c(full["dx"][:chunk]), b["dkey"] + b["dvalue"]) < BF16_BOUNDS["dx"]
     m = O.curriculum_mask_train(f["wbar"], U[:chunk], 0.15)
     agree = ((c(full["mw"][:chunk]) != 0) == (m["masked"] != 0)).float().mean()
     assert float(agree) > 0.999          # identical except where |U - keep| is below the float32 noise of wbar

@@ -4,7 +4,7 @@ with and without key_padding_mask / gradient on the attention weights.  Checked 
 import pytest
 import torch
 
-from tests.helpers import rel_err
+from tests.helpers import BF16_F32GRAD_BOUNDS, assert_bf16_bounds, record_errors, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -75,6 +75,8 @@ def _case(B, M, E, H, dtype, kpm, seed):
     want = dict(y=f["y"], wbar=f["wbar"], dx=b["dkey"] + b["dvalue"], dw_in=b["dw_in"], db_in=b["db_in"],
                 dw_out=b["dw_out"], db_out=b["db_out"], dq=b["dquery"].sum(0, keepdim=True))
     errs = {k: rel_err(got[k], want[k]) for k in got}
+    if dtype != torch.float32:
+        record_errors(f"sweep:B{B}_M{M}_E{E}_H{H}_{'kpm' if kpm else 'nomask'}", **errs)
     # masking of the kernel's own weights (the oracle on the kernel's float32 weights is the contract)
     if M > 1:
         m = O.curriculum_mask_train(c(info["attention_weights"]) if dtype == torch.float32 else f["wbar"], U, 0.3)
@@ -103,14 +105,9 @@ def test_shapes_bf16(shape, kpm):
     if kpm and M == 1:
         pytest.skip("a single modality cannot be padded away")
     errs, agree = _case(B, M, E, H, torch.bfloat16, kpm, seed=B + M + E + H + 1)
-    tol = 1e-3 + 2.0 ** -8
-    for k in ("y", "wbar", "dx"):
-        assert errs[k] < tol, (shape, k, errs[k])
-    for k in ("dw_in", "db_in", "dw_out", "db_out"):                # float32 outputs of the bf16 kernels
-        assert errs[k] < 4e-3, (shape, k, errs[k])
-    # dquery = W_q^T (scale W_k u), u = ds^T x: ds comes from dots of bf16 do and bf16 V and sums to zero over the
-    # modalities, so u is a cancellation of bf16-rounded terms -- the loosest of the bf16 outputs (4.3e-3 at B=1100)
-    assert errs["dq"] < 6e-3, (shape, "dq", errs["dq"])
+    # per tensor (tests/helpers.py): dquery = W_q^T (scale W_k u), u = ds^T x is a cancellation of bf16-rounded terms (ds
+    # sums to zero over the modalities) -- the loosest of the outputs (4.4e-3 measured)
+    assert_bf16_bounds(errs, BF16_F32GRAD_BOUNDS, shape)
     assert agree > 0.99
 
 
@@ -133,10 +130,11 @@ print("RESULT " + json.dumps(dict(errs=errs, agree=agree)))
 """
 
 
-@pytest.mark.parametrize("knobs", [{"AECF_NO_WS": "1"}, {"AECF_NO_GATE_FUSION": "1"}, {"AECF_NO_WIDE_TN": "1"},
-                                   {"AECF_GRAPH": "0"}, {"AECF_FUSED_FWD": "1"}, {"AECF_PM": "1"}, {"AECF_NO_SLAB": "1"}],
+@pytest.mark.parametrize("knobs", [{"AECF_DEBUG": "no_ws"}, {"AECF_DEBUG": "no_gate_fusion"}, {"AECF_DEBUG": "no_wide_tn"},
+                                   {"AECF_DEBUG": "graph=0"}, {"AECF_DEBUG": "fused_fwd"}, {"AECF_DEBUG": "no_slab"},
+                                   {"AECF_DEBUG": "no_ws,graph=1"}],
                          ids=["tiled", "separate_gate", "narrow_batch_reduction", "plain_launches", "one_kernel_forward",
-                              "matrix_pipe_pooling", "two_barrier_gate"])
+                              "two_barrier_gate", "tiled_as_graph"])
 def test_bf16_fallback_kernels_at_the_hot_path_shape(knobs):
     """The kernels that serve shapes the weight-stationary engine does not take (tiled NT GEMM, per-modality value
     projection, stand-alone gate, tiled dx) stay correct at d=512 / 8 heads / M=3: the library's A/B switches route the
@@ -151,12 +149,7 @@ def test_bf16_fallback_kernels_at_the_hot_path_shape(knobs):
                          text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
-    tol = 1e-3 + 2.0 ** -8
-    for k in ("y", "wbar", "dx"):
-        assert res["errs"][k] < tol, (k, res["errs"][k])
-    for k in ("dw_in", "db_in", "dw_out", "db_out"):
-        assert res["errs"][k] < 4e-3, (k, res["errs"][k])
-    assert res["errs"]["dq"] < 6e-3
+    assert_bf16_bounds(res["errs"], BF16_F32GRAD_BOUNDS, sorted(knobs))
     assert res["agree"] > 0.99
 
 
@@ -204,8 +197,8 @@ def test_graph_replay_back_to_back():
     import sys
     from tests.helpers import ROOT
     digests = {}
-    for name, knobs in (("plain", {"AECF_GRAPH": "0"}), ("graph", {"AECF_GRAPH": "1", "HIP_FORCE_DEV_KERNARG": "0"}),
-                        ("graph_devkernarg", {"AECF_GRAPH": "1", "HIP_FORCE_DEV_KERNARG": "1"}),
+    for name, knobs in (("plain", {"AECF_DEBUG": "graph=0"}), ("graph", {"AECF_DEBUG": "graph=1", "HIP_FORCE_DEV_KERNARG": "0"}),
+                        ("graph_devkernarg", {"AECF_DEBUG": "graph=1", "HIP_FORCE_DEV_KERNARG": "1"}),
                         ("default", {})):
         env = dict(os.environ, **knobs)
         out = subprocess.run([sys.executable, "-c", _GRAPH_SCRIPT.format(root=ROOT)], env=env, capture_output=True,

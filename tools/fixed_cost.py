@@ -3,7 +3,7 @@ launch whatever the batch (launch, weight prologue, first tile, tail)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-os.environ.setdefault("AECF_GRAPH", "0")
+os.environ.setdefault("AECF_DEBUG", "graph=0")
 import torch
 import bench
 
