@@ -220,9 +220,10 @@ class GradOverlap:
     With this object installed (as ``layer._param_grads_hook``) the backward computes dx last and the library announces
     the moment the five parameter gradients are final with a HIP event (aecf_pool_bwd_args.param_grads_event); a side
     stream waits for that event and issues ONE collective there, in place on the gradient allocation, while the dx
-    kernel runs on the caller's stream.  ``finish`` makes the current stream wait for every collective issued that way
-    (one per fused backward: two pool layers, or two backward calls of an accumulation step, give two) and reduces, the
-    plain way, any parameters they did not cover.  Use:
+    kernel runs on the caller's stream.  ``finish`` makes the current stream wait for it and reduces, the plain way, any
+    parameters it did not cover.  A second fused backward inside one region (two applications of the pool feeding one loss)
+    is reduced too, but on the main stream and after the first collective has completed: autograd adds its gradients into
+    the first one's allocation, which nothing may be mutating meanwhile.  Use:
 
         overlap = dp.GradOverlap(params=params)
         with overlap:                 # installs / removes the hook
@@ -265,6 +266,18 @@ class GradOverlap:
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def __call__(self, flat: torch.Tensor, event) -> None:
+        if self.pending:
+            # A SECOND fused backward inside one region (two pool applications, or two backward() calls): autograd is about
+            # to ADD this call's gradients into the p.grad the first call left -- on the main stream, reading both allocations.
+            # Nothing may mutate them behind its back: the first collective is waited for here and this one runs on the main
+            # stream (no overlap for it); the sum autograd forms is then the sum of two reduced gradients.
+            for _, work in self.pending:
+                if work is not None:
+                    work.wait()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self._reduce(flat, async_op=False)
+            self.pending.append((flat, None))
+            return
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=flat.device)
         self.stream.wait_event(event)                       # the gradients are final once the library's event has fired
@@ -285,7 +298,8 @@ class GradOverlap:
             return
         spans = []
         for flat, work in pending:
-            work.wait()
+            if work is not None:
+                work.wait()
             spans.append((flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
         torch.cuda.current_stream().wait_stream(self.stream)
         rest = [p for p in params if not any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]

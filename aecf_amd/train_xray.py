@@ -113,9 +113,10 @@ def main(argv=None):
     opt = torch.optim.AdamW(params, lr=args.lr, weight_decay=0.01)          # ref :322-323
     crit = torch.nn.BCEWithLogitsLoss()
     n = image.shape[0]
-    steps = n // args.batch
+    steps = (n + args.batch - 1) // args.batch                              # the short last batch is kept (DataLoader default)
     perm_gen = torch.Generator(device=device).manual_seed(args.seed + 3)    # same permutation on every rank
     mask_gen = torch.Generator(device=device).manual_seed(args.seed + 4)    # same global mask uniforms on every rank
+    miss_gen = torch.Generator(device=device).manual_seed(args.seed + 5)    # same global missing-modality draws on every rank
     history = []
     for epoch in range(args.epochs):
         if epoch == args.switch_epoch:                                      # ref :346-349
@@ -128,16 +129,26 @@ def main(argv=None):
         ent_sum = torch.zeros((), device=device)
         for it in range(steps):
             idx = perm[it * args.batch:(it + 1) * args.batch]
-            lo, hi = dp.shard_bounds(args.batch, rank, world)
+            b = idx.numel()                                                 # < args.batch in the last step of an epoch
+            lo, hi = dp.shard_bounds(b, rank, world)
             sel = idx[lo:hi]
-            u = torch.rand(args.batch, 1, 2, device=device, generator=mask_gen)[lo:hi]
-            logits, info = model(image[sel], text[sel], return_info=True, mask_uniforms=u)
+            u = torch.rand(b, 1, 2, device=device, generator=mask_gen)[lo:hi]       # (every rank draws: the streams stay aligned)
+            missing = None
+            if model.missing_modality_training:
+                da, db = model.draw_missing(b, device, generator=miss_gen)  # the GLOBAL batch's draws; this rank's rows
+                missing = (da[lo:hi], db[lo:hi])
+            if hi <= lo:                                # fewer rows than ranks: this rank only joins the collective
+                bucket.zero()
+                bucket.all_reduce(average=True)
+                opt.step()
+                continue
+            logits, info = model(image[sel], text[sel], return_info=True, mask_uniforms=u, missing=missing)
             loss = crit(logits, labels[sel])
             if bucket is None:
                 opt.zero_grad(set_to_none=True)
             else:
                 bucket.zero()
-            (loss * dp.shard_loss_scale(hi - lo, args.batch, world)).backward()
+            (loss * dp.shard_loss_scale(hi - lo, b, world)).backward()
             if bucket is not None:
                 bucket.all_reduce(average=True)
             opt.step()

@@ -216,11 +216,18 @@ class AECFModel(nn.Module):
         return drop_a & ~(clash & keep_a), drop_b & ~(clash & ~keep_a)
 
     def forward(self, image_features: torch.Tensor, text_features: torch.Tensor, return_info: bool = False, *,
-                mask_uniforms: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
-        """``mask_uniforms`` / ``generator`` are handed to the pool's curriculum masking (``[n_both, 1, 2]``)."""
+                mask_uniforms: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
+                missing: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """``mask_uniforms`` / ``generator`` are handed to the pool's curriculum masking (``[n_both, 1, 2]``).  ``missing`` =
+        (drop_a, drop_b) for this call's rows, drawn by the caller: a data-parallel trainer draws them for the GLOBAL batch from
+        a shared-seed generator (``draw_missing``) and hands every rank its rows, so that which rows lose a modality does not
+        depend on the number of ranks (as for the mask uniforms); without it they are drawn here."""
         drop_a = drop_b = None
         if self.training and self.missing_modality_training:
-            drop_a, drop_b = self.draw_missing(image_features.size(0), image_features.device, generator=generator)
+            if missing is not None:
+                drop_a, drop_b = missing
+            else:
+                drop_a, drop_b = self.draw_missing(image_features.size(0), image_features.device, generator=generator)
         image_features, has_a = modality_frontend(image_features, drop_a)
         text_features, has_b = modality_frontend(text_features, drop_b)
         route = Route(has_a, has_b)
