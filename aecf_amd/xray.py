@@ -188,6 +188,11 @@ class AECFModel(nn.Module):
         self.hidden_dim = hidden_dim
         self.curriculum_enabled = False
         self.missing_modality_training = False
+        # static_routing: every branch processes EVERY row and a per-row select keeps the owner's result -- no class sizes are
+        # read back, every shape is fixed by the batch size, so a whole training step can be captured as one HIP graph
+        # (GraphedTrainStep below).  Same logits, loss and parameter gradients as the compact routing (rows outside a branch
+        # get a zero upstream gradient); info tensors then cover all rows (info["both"] marks the rows that have both).
+        self.static_routing = False
         enc = lambda d: nn.Sequential(nn.Linear(d, hidden_dim), nn.ReLU(), nn.Dropout(0.1))
         self.image_encoder = enc(image_dim)
         self.text_encoder = enc(text_dim)
@@ -230,6 +235,8 @@ class AECFModel(nn.Module):
                 drop_a, drop_b = self.draw_missing(image_features.size(0), image_features.device, generator=generator)
         image_features, has_a = modality_frontend(image_features, drop_a)
         text_features, has_b = modality_frontend(text_features, drop_b)
+        if self.static_routing:
+            return self._forward_static(image_features, text_features, has_a, has_b, return_info, mask_uniforms, generator)
         route = Route(has_a, has_b)
         enc_a = self.image_encoder(image_features)
         enc_b = self.text_encoder(text_features)
@@ -258,6 +265,74 @@ class AECFModel(nn.Module):
         fused = _BranchSelect.apply(from_both, from_a, from_b, route, width)
         logits = self.classifier(fused)
         return (logits, info) if return_info else logits
+
+
+def _forward_static(self, image_features, text_features, has_a, has_b, return_info, mask_uniforms, generator):
+    rows = image_features.size(0)
+    a, b = has_a.bool(), has_b.bool()
+    enc_a = self.image_encoder(image_features)
+    enc_b = self.text_encoder(text_features)
+    pairs = torch.stack([enc_a, enc_b], dim=1)                                   # [rows, 2, E] (what ref :213-214 stacks)
+    pooled, pool_info = self.attention_pool(self.fusion_query.expand(rows, -1, -1), pairs, pairs, return_info=True,
+                                            uniforms=mask_uniforms, generator=generator)
+    dt = enc_a.dtype
+    m_both, m_a, m_b = (a & b).to(dt).unsqueeze(1), (a & ~b).to(dt).unsqueeze(1), (b & ~a).to(dt).unsqueeze(1)
+    fused = self.fusion_proj(pooled.squeeze(1)) * m_both + self.image_proj(enc_a) * m_a + self.text_proj(enc_b) * m_b
+    logits = self.classifier(fused)
+    if not return_info:
+        return logits
+    info = dict(pool_info)
+    info["both"] = a & b
+    return logits, info
+
+
+AECFModel._forward_static = _forward_static
+
+
+class GraphedTrainStep:
+    """One optimisation step of ``AECFModel`` (zero_grad, forward, BCE, backward, AdamW: ref xrays/train_xrays_example.py:360-377)
+    captured ONCE as a HIP graph and replayed per batch.  The eager step is ~50 launches of a few microseconds of device work
+    each plus one device->host read: at the reference's batch of 64 the host's launch rate is the whole step time (1.9 ms,
+    profiles/r03_c4_b64_bench.json).  Static routing (no class sizes read back) makes every shape a function of the batch
+    size alone; the batch, labels and the returned loss live in fixed buffers that a replay reads and writes.
+
+    Randomness (curriculum mask, missing-modality draws) comes from the device's default generator, whose offset a replay
+    advances; the optimizer must be constructed ``capturable=True``.  One rank only: the captured step has no collective
+    (data-parallel callers capture per rank and all-reduce between backward and step themselves)."""
+
+    def __init__(self, model: AECFModel, optimizer: torch.optim.Optimizer, criterion: nn.Module, batch: int, image_dim: int,
+                 text_dim: int, num_classes: int, device, dtype=torch.float32, warmup: int = 3):
+        model.static_routing = True
+        self.model, self.optimizer, self.criterion = model, optimizer, criterion
+        self.image = torch.zeros(batch, image_dim, device=device, dtype=dtype)
+        self.text = torch.zeros(batch, text_dim, device=device, dtype=dtype)
+        self.labels = torch.zeros(batch, num_classes, device=device, dtype=dtype)
+        self.image.normal_()
+        self.text.normal_()
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                        # warm-up on a side stream (allocator, lazily built state)
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._step()
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        logits = self.model(self.image, self.text)
+        loss = self.criterion(logits, self.labels)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, images: torch.Tensor, texts: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        self.image.copy_(images, non_blocking=True)
+        self.text.copy_(texts, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        self.graph.replay()
+        return self.loss
 
 
 def train_step(model: AECFModel, optimizer: torch.optim.Optimizer, criterion: nn.Module, images: torch.Tensor,

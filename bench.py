@@ -311,10 +311,21 @@ def bench_c4(args):
     if world > 1:
         dp.broadcast_parameters(params + list(model.buffers()))
     bucket = dp.FlatGradBucket(params) if world > 1 else None
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
-    crit = torch.nn.BCEWithLogitsLoss()
+    graphed = None
+    if args.graph:
+        if world > 1:
+            sys.exit("--graph captures a one-rank step")
+        from aecf_amd.xray import GraphedTrainStep
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, capturable=True)
+        crit = torch.nn.BCEWithLogitsLoss()
+        graphed = GraphedTrainStep(model, opt, crit, B, 512, 512, 15, device)
+    else:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
+        crit = torch.nn.BCEWithLogitsLoss()
 
     def one_step():
+        if graphed is not None:
+            return graphed(image, text, labels)
         return train_step(model, opt, crit, image, text, labels, bucket)
 
     def barrier():
@@ -345,14 +356,17 @@ def bench_c4(args):
             "ms_per_step": sec * 1e3, "steps_per_s": 1.0 / sec, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"c4: example model step (encoders, presence routing, pool [M=2, d=256, 4 heads], classifier, BCE, "
-                                   f"AdamW), batch {B} per GPU, curriculum masking + missing-modality training on",
+                                   f"AdamW), batch {B} per GPU, curriculum masking + missing-modality training on"
+                                   + (", the step replayed as ONE captured HIP graph (static routing)" if graphed is not None else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}", "world_size": world,
                        "collectives": None if world == 1 else f"{backend}: one flat all-reduce of all {sum(p.numel() for p in params)} gradients"},
             "roofline": None,
             "host_enqueue_ms": enqueue / args.steps * 1e3,
             "device_tail_ms": max(0.0, (elapsed - enqueue) / args.steps * 1e3),
-            "note": "host-bound: the step is ~50 small launches (4 nn.Linear layers each way, routing, pool, AdamW) and one "
-                    "device->host read of the routing counts; host_enqueue_ms ~ ms_per_step means the GPU waits for the host",
+            "note": ("one graph replay per step: the host only copies the batch into the captured buffers and launches the graph; "
+                     "what is left is the device walking the graph's kernel nodes" if graphed is not None else
+                     "host-bound: the step is ~50 small launches (4 nn.Linear layers each way, routing, pool, AdamW) and one "
+                     "device->host read of the routing counts; host_enqueue_ms ~ ms_per_step means the GPU waits for the host"),
             "cpu_baseline": None,
         }
         print(json.dumps(line), flush=True)
@@ -368,6 +382,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["c4"])
     ap.add_argument("--batch", type=int, default=64, help="--config c4: rows per step per GPU (the reference's 64)")
+    ap.add_argument("--graph", action="store_true", help="--config c4: the step captured once as a HIP graph (one rank)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = B per GPU fixed (default), strong = the config's B is the GLOBAL batch, sharded")
     ap.add_argument("--contrastive", action="store_true",
