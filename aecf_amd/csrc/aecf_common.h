@@ -149,10 +149,11 @@ struct MaskCfg {
 // x*log(x) with xlogy semantics: 0 at x==0, NaN propagates (torch.xlogy, ref :125)
 __device__ __forceinline__ float xlogx(float w) { return (w == 0.f) ? 0.f : w * logf(w); }
 
-template <int LMAX>
+// BITS: the word that holds one keep bit per key (unsigned int up to 32 keys, unsigned long long up to 64)
+template <int LMAX, typename BITS = unsigned int>
 __device__ __forceinline__ void curriculum_row(const MaskCfg& c, int L, float* w /*in: weights, out: normalised*/,
                                                const float* u, float* masked, float& entropy, float& mask_rate,
-                                               unsigned int& mask_bits) {
+                                               BITS& mask_bits) {
     const float logL = c.log_L;
     if (c.mode == 2) {  // eval (ref :150-156): weights unchanged, entropy of the raw weights
         float h = 0.f;
@@ -162,14 +163,14 @@ __device__ __forceinline__ void curriculum_row(const MaskCfg& c, int L, float* w
         entropy = fminf(fmaxf(h, 0.f), logL);
         if (h != h) entropy = h;
         mask_rate = 0.f;
-        mask_bits = 0xffffffffu;
+        mask_bits = ~(BITS)0;
         return;
     }
     if (L <= 1) {  // ref :160-167
         masked[0] = w[0];
         entropy = 0.f;
         mask_rate = 0.f;
-        mask_bits = 1u;
+        mask_bits = (BITS)1;
         return;
     }
     // ref :170-184  (non-finite entries -> 0; rows summing below eps -> uniform; else w / sum)
@@ -194,22 +195,22 @@ __device__ __forceinline__ void curriculum_row(const MaskCfg& c, int L, float* w
     float ne = fminf(fmaxf(h / logL, 0.f), 1.f);
     float keep = fminf(fmaxf(1.0f - c.base_mask_prob * ne, 0.f), 1.f);
     // ref :204  bernoulli(keep) == (u < keep) on the float32 uniform stream
-    unsigned int bits = 0u;
+    BITS bits = 0;
     int active = 0;
 #pragma unroll
     for (int i = 0; i < LMAX; ++i)
-        if (i < L && u[i] < keep) { bits |= (1u << i); ++active; }
+        if (i < L && u[i] < keep) { bits |= ((BITS)1 << i); ++active; }
     // ref :207-260  min-active fix: rows with too few survivors keep exactly their top-k weights
     const int k = c.min_active < L ? c.min_active : L;
     if (active < k) {
-        bits = 0u;
+        bits = 0;
         for (int t = 0; t < k; ++t) {   // k selections of the largest remaining, lowest index on ties
             int best = -1;
             float bv = 0.f;
 #pragma unroll
             for (int i = 0; i < LMAX; ++i)
-                if (i < L && !((bits >> i) & 1u) && (best < 0 || w[i] > bv)) { best = i; bv = w[i]; }
-            bits |= (1u << best);
+                if (i < L && !((bits >> i) & 1) && (best < 0 || w[i] > bv)) { best = i; bv = w[i]; }
+            bits |= ((BITS)1 << best);
         }
         active = k;
     }
@@ -217,7 +218,7 @@ __device__ __forceinline__ void curriculum_row(const MaskCfg& c, int L, float* w
     float ms = 0.f;
 #pragma unroll
     for (int i = 0; i < LMAX; ++i)
-        if (i < L) { masked[i] = ((bits >> i) & 1u) ? w[i] : 0.f; ms += masked[i]; }
+        if (i < L) { masked[i] = ((bits >> i) & 1) ? w[i] : 0.f; ms += masked[i]; }
     const bool valid = ms > c.eps;
 #pragma unroll
     for (int i = 0; i < LMAX; ++i)

@@ -1,5 +1,6 @@
 // Stand-alone pieces of the AECF surface: CurriculumMasking forward/backward on free-standing weight
 // rows, entropy_loss forward+backward, projection-free single-head attention.  gfx950.
+#include <type_traits>
 #include "aecf_kernels.h"
 
 namespace aecf {
@@ -21,13 +22,14 @@ __global__ __launch_bounds__(256) void mask_fwd_kernel(int64_t rows, int L, Mask
         mk[i] = 0.f;
     }
     float ent, rate;
-    unsigned int bits;
-    curriculum_row<LMAX>(cfg, L, wv, uv, mk, ent, rate, bits);
+    typedef typename std::conditional<(LMAX > 32), unsigned long long, unsigned int>::type bits_t;
+    bits_t bits;
+    curriculum_row<LMAX, bits_t>(cfg, L, wv, uv, mk, ent, rate, bits);
 #pragma unroll
     for (int i = 0; i < LMAX; ++i)
         if (i < L) {
             if (masked) masked[row * L + i] = mk[i];
-            if (bits_out) bits_out[row * L + i] = (uint8_t)((bits >> i) & 1u);
+            if (bits_out) bits_out[row * L + i] = (uint8_t)((bits >> i) & 1);
         }
     if (entropy) entropy[row] = ent;
     if (mask_rate) mask_rate[row] = rate;
@@ -235,7 +237,8 @@ void launch_mask_fwd(int64_t rows, int L, const MaskCfg& cfg, const float* w, co
     if (L <= 4) mask_fwd_kernel<4><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
     else if (L <= 8) mask_fwd_kernel<8><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
     else if (L <= 16) mask_fwd_kernel<16><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
-    else mask_fwd_kernel<32><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
+    else if (L <= 32) mask_fwd_kernel<32><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
+    else mask_fwd_kernel<64><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);     // 64-bit keep word
 }
 
 void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, const float* w, const uint8_t* bits,
@@ -244,7 +247,8 @@ void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, cons
     if (L <= 4) mask_bwd_kernel<4><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
     else if (L <= 8) mask_bwd_kernel<8><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
     else if (L <= 16) mask_bwd_kernel<16><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
-    else mask_bwd_kernel<32><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
+    else if (L <= 32) mask_bwd_kernel<32><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
+    else mask_bwd_kernel<64><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
 }
 
 // ------------------------------------------------------------------------------------------

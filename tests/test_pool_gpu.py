@@ -433,8 +433,37 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(RuntimeError, match="not supported"):
         pool40(torch.randn(1, 1, 40, device=dev).expand(4, -1, -1), torch.randn(4, 3, 40, device=dev))
     cm = aecf_amd.CurriculumMasking().to(dev).train()
-    with pytest.raises(NotImplementedError, match="32 keys"):                   # the mask kernels keep a row in registers
-        cm(torch.softmax(torch.randn(4, 1, 40, device=dev), -1))
+    with pytest.raises(NotImplementedError, match="64 keys"):                   # the mask kernels keep a row in registers
+        cm(torch.softmax(torch.randn(4, 1, 70, device=dev), -1))
+
+
+@pytest.mark.parametrize("L", [33, 40, 64])
+def test_curriculum_masking_over_33_to_64_keys(L):
+    """The stand-alone masking takes up to 64 keys (a 64-bit keep word per row; the reference is length-agnostic,
+    aecf/AECFLayer.py:130-283): mask pattern bit-exact, weights / entropy / mask rate and the gradient against the oracle."""
+    import aecf_amd
+    from oracle import aecf_oracle as O
+    dev = _dev()
+    g = torch.Generator().manual_seed(L)
+    w = torch.softmax(torch.randn(300, 1, L, generator=g) * 2.0, -1)
+    U = torch.rand(300, 1, L, generator=g)
+    for min_active in (1, 3):
+        cm = aecf_amd.CurriculumMasking(base_mask_prob=0.6, min_active=min_active).to(dev).train()
+        wd = w.to(dev).requires_grad_(True)
+        masked, info = cm(wd, uniforms=U.to(dev))
+        want = O.curriculum_mask_train(w, U, 0.6, min_active=min_active)
+        assert torch.equal(masked.detach().cpu() != 0, want["masked"] != 0)
+        assert rel_err(masked.detach().cpu(), want["masked"]) < 1e-6
+        assert rel_err(info["entropy"].cpu(), want["entropy"]) < 1e-6
+        assert rel_err(info["mask_rate"].cpu(), want["mask_rate"]) < 1e-6
+        dm = torch.randn(300, 1, L, generator=g)
+        (masked * dm.to(dev)).sum().backward()
+        wr = w.clone().requires_grad_(True)                 # autograd of the same arithmetic with the mask held fixed
+        keep = (want["masked"] != 0).float()
+        wn = wr / wr.sum(-1, keepdim=True)
+        mm = wn * keep
+        (mm / mm.sum(-1, keepdim=True) * dm).sum().backward()
+        assert rel_err(wd.grad.cpu(), wr.grad) < 1e-5
 
 
 def test_shapes_outside_the_shared_query_kernels_use_the_general_path():
