@@ -135,8 +135,17 @@ class _NceSymmetric(torch.autograd.Function):
         return (da * g).to(ad), (db * g).to(bd), g_ent, None, None, None, None, None, None
 
 
-def _sym_supported(z: torch.Tensor, temperature: float) -> bool:
-    return z.dtype == torch.bfloat16 and z.shape[1] % 64 == 0 and temperature >= 0.025
+def _sym_supported(z: torch.Tensor, temperature: float, cols: Optional[int] = None) -> bool:
+    """The tile-GEMM form applies (bf16, d % 64 == 0, 1/T a safe exponent shift) AND its workspace -- rows x cols bf16 -- fits
+    comfortably in what the device has free; otherwise the callers take the streaming kernels (O(rows d) workspace)."""
+    if not (z.dtype == torch.bfloat16 and z.shape[1] % 64 == 0 and temperature >= 0.025):
+        return False
+    if cols is not None and z.is_cuda:
+        need = _lib.load().aecf_nce_sym_workspace_bytes(z.shape[0], cols, z.shape[1])
+        free, _ = torch.cuda.mem_get_info(z.device)
+        if need > 0.6 * free:
+            return False
+    return True
 
 
 class _LossDirection(torch.autograd.Function):
@@ -184,7 +193,7 @@ def contrastive_entropy_loss(za: torch.Tensor, zb: torch.Tensor, masking: Curric
     na, nb = l2_normalize(za), l2_normalize(zb)
     coef = 0.5 / float(za.shape[0])
     seq_len = masking._last_seq_len if hasattr(masking, "_last_seq_len") else 2
-    if _sym_supported(za, temperature):
+    if _sym_supported(za, temperature, za.shape[0]):
         l_nce, l_ent = _NceSymmetric.apply(na, nb, entropy, 0, float(temperature), coef, None, int(seq_len),
                                            float(masking.entropy_target))
         return contrastive_weight * l_nce + entropy_weight * l_ent.to(za.dtype)
@@ -232,9 +241,13 @@ def info_nce(za: torch.Tensor, zb: torch.Tensor, temperature: float = 0.07, grou
         raise NotImplementedError(f"aecf_amd: dtype {za.dtype} is not supported (bfloat16 / float32 only)")
     rank, world = dp.world_info(group)
     na, nb = l2_normalize(za), l2_normalize(zb)
-    sym = _sym_supported(za, temperature)
     nb_all = dp.all_gather_rows(nb, group) if world > 1 else nb
     b_all = nb_all.shape[0]
+    sym = _sym_supported(za, temperature, b_all)
+    if world > 1:                                   # every rank must take the same form (they exchange different things)
+        flag = torch.tensor([1 if sym else 0], device=za.device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
+        sym = bool(int(flag.item()))
     if world > 1:
         sizes = torch.tensor([za.shape[0]], device=za.device)
         all_sizes = [torch.zeros_like(sizes) for _ in range(world)]

@@ -382,7 +382,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["c4"])
     ap.add_argument("--batch", type=int, default=64, help="--config c4: rows per step per GPU (the reference's 64)")
-    ap.add_argument("--graph", action="store_true", help="--config c4: the step captured once as a HIP graph (one rank)")
+    ap.add_argument("--graph", action="store_true",
+                    help="one rank: the whole step captured once as a HIP graph and replayed (c4: static routing; the pool "
+                         "configurations: forward + entropy loss + backward; meant for the host-bound shards)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = B per GPU fixed (default), strong = the config's B is the GLOBAL batch, sharded")
     ap.add_argument("--contrastive", action="store_true",
@@ -480,6 +482,24 @@ def main():
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    graph = None
+    if args.graph:
+        if world > 1:
+            sys.exit("--graph captures a one-rank step")
+        eager_step = one_step
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eager_step()
+
+        def one_step():
+            graph.replay()
 
     # A fresh process needs ~25 steps (~15 ms) before its step time settles (tools/step_trend.py: 0.66, 0.65 ... 0.59 ms; 300 ms
     # of unrelated device work beforehand does not shorten it): SETTLE_STEPS untimed steps come first and are reported in the line
@@ -615,6 +635,7 @@ def main():
             "path_mfma_frac": path_flops * B / sec / 1e12 / MFMA_PEAK_TFLOPS,
             "stage_ms": stages,
             "stage_pass": {"steps": STAGE_PASS_STEPS, "when": "after the timed region", "stat": "median"},
+            "graph_replay": graph is not None,
             "cpu_baseline": cb,
         }
         print(json.dumps(line), flush=True)

@@ -77,3 +77,19 @@ def test_graphed_train_step_equals_eager_steps():
         assert abs(a - b) < 1e-4 * max(1.0, abs(a)), (losses_e, losses_g)
     for p, q in zip(eager.parameters(), graphed_model.parameters()):
         assert rel_err(q.detach().cpu(), p.detach().cpu()) < 1e-4
+
+
+@pytest.mark.timeout(300)
+def test_bench_pool_step_replays_as_one_graph():
+    """`bench.py --graph`: the pool forward + entropy loss + backward captured once by torch.cuda.graphs (the library's launches
+    join the caller's capture) and replayed -- what makes the host-bound shards device-bound."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--graph", "--steps", "20", "--warmup", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["graph_replay"] is True and line["value"] > 0
