@@ -9,8 +9,9 @@ x[B=65536, M=3, d=512] bf16, 8 heads, mask_prob 0.15, curriculum masking in trai
 One "step" = pool(query.expand(B), x, return_info=True) + entropy_loss(info['entropy']) + backward with a
 resident upstream gradient dy, all inputs resident in HBM.  N>1: one process per GPU; `--scaling weak` (default)
 gives every rank its own B samples, `--scaling strong` shards the global B=65536 across the ranks; the parameter
-gradients (4E^2+5E values) are all-reduced over RCCL inside the step and every rank consumes ITS rows of one global
-uniform tensor for the curriculum mask (N-rank masks == 1-rank masks).
+gradients (4E^2+5E values) are all-reduced over RCCL inside the step (ONE collective, in place, after the backward; `--overlap`
+issues it behind the dx kernel instead -- experimental) and every rank consumes ITS rows of one global uniform tensor for the
+curriculum mask (N-rank masks == 1-rank masks; drawing the global tensor is inside the timed step: ~4 us at N = 1, ~10 us at N = 8).
 
 `--config c3 --contrastive` (BASELINE configs[2]: "2-modality d=768 with cross-batch contrastive all-gather"): the step is the
 pool forward on the rank's [8192, 2, 768] rows, the symmetric InfoNCE of the fused rows against the 65536 gathered rows of the
@@ -75,7 +76,7 @@ def make_inputs(cfg, device, seed_offset=0):
 def step(pool, query, x, dy, params, dp_on, uniforms=None, overlap=None):
     """One pass of the hot path over one resident batch: forward (+ entropy_loss) + backward (+ the gradient all-reduce
     when data-parallel: ONE collective, issued behind the backward's last kernel (dx) on a side stream, dp.GradOverlap;
-    --no-overlap: the same collective after the backward)."""
+    default: the same collective after the backward)."""
     B = x.shape[0]
     out, info = pool(query.expand(B, -1, -1), x, return_info=True, uniforms=uniforms)
     ent_loss = pool.curriculum_masking.entropy_loss(info["entropy"])
@@ -390,7 +391,11 @@ def main():
     ap.add_argument("--contrastive", action="store_true",
                     help="configs[2]: add the symmetric InfoNCE against 65536 gathered keys (+ entropy loss) to the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="N>1: one gradient all-reduce after the backward")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N>1: issue the gradient all-reduce behind the backward's dx kernel on a side stream (dp.GradOverlap: "
+                         "EXPERIMENTAL -- never run over RCCL on real multi-GPU hardware by this build; default: one all-reduce "
+                         "after the backward)")
+    ap.add_argument("--no-overlap", action="store_true", help="(default behaviour; kept for older command lines)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -429,7 +434,7 @@ def main():
         dp.probe_avg_support(params[0].dtype, device)
     # curriculum-mask uniforms: every rank draws the SAME global tensor (shared seed, own generator) and uses its rows
     ugen = torch.Generator(device=device).manual_seed(1234) if world > 1 else None
-    overlap = dp.GradOverlap() if (world > 1 and not args.no_overlap) else None
+    overlap = dp.GradOverlap(params=params) if (world > 1 and args.overlap and not args.no_overlap) else None
 
     # --contrastive (configs[2]): the paired view.  zb_local = this rank's rows of the other view (resident, as the output of a
     # second tower would be); N = 1: the 65536 gathered unit-norm keys are resident too (rank 3 of 8: offset 3 x 8192) and the
