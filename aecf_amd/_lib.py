@@ -135,9 +135,12 @@ _SYMBOLS = [
     ("aecf_nce_sym_workspace_bytes", c_size_t, [c_int64, c_int64, c_int32]),
     ("aecf_nce_sym_pass1", c_int,
      [c_int64, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
-    ("aecf_nce_sym_pass2", c_int,
-     [c_int64, c_int64, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
-      c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    ("aecf_nce_sym_loss", c_int,
+     [c_int64, c_int64, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int64,
+      c_int32, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    ("aecf_nce_sym_grads", c_int,
+     [c_int64, c_int64, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int32,
+      c_void_p, c_void_p, c_void_p]),
     ("aecf_nce_fwd_bwd", c_int,
      [c_int64, c_int64, c_int64, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -817,8 +817,10 @@ int aecf_loss_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d,
     const float* ent = n_entropy > 0 ? entropy : nullptr;
     if (nce_gemm_supported(AECF_BF16, d, temperature) && workspace_bytes >= nce_gemm_workspace_bytes(rows, cols, d)) {
         launch_nce_gemm_pass1(rows, cols, d, 1.0f / temperature, q, k, workspace, nullptr, (hipStream_t)stream);
-        launch_nce_gemm_pass2(rows, cols, row_offset, d, 1.0f / temperature, coef, 0, q, k, nullptr, workspace, loss_rows, dq, dk,
-                              ent, n_entropy, ent_t, entropy_upstream, d_entropy, entropy_loss, (hipStream_t)stream);
+        launch_nce_gemm_loss(rows, cols, row_offset, d, 1.0f / temperature, 0, q, k, nullptr, workspace, loss_rows, ent, n_entropy,
+                             ent_t, entropy_upstream, d_entropy, entropy_loss, (hipStream_t)stream);
+        launch_nce_gemm_grads(rows, cols, row_offset, d, 1.0f / temperature, coef, 0, q, k, workspace, nullptr, 0, dq, dk,
+                              (hipStream_t)stream);
         return launch_status();
     }
     if (!nce_flash_supported(AECF_BF16, d)) return AECF_ERR_UNSUPPORTED;
@@ -843,20 +845,34 @@ int aecf_nce_sym_pass1(int64_t rows, int64_t cols, int32_t d, float temperature,
     return launch_status();
 }
 
-int aecf_nce_sym_pass2(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef, const void* a,
-                       const void* b, const float* col_sums, void* workspace, size_t workspace_bytes, float* loss_rows, float* da,
-                       float* db, int64_t n_entropy, int32_t last_seq_len, float entropy_target, const float* entropy,
-                       float entropy_upstream, float* entropy_loss, float* d_entropy, void* stream) {
+int aecf_nce_sym_loss(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, const void* a, const void* b,
+                      const float* col_sums, void* workspace, size_t workspace_bytes, float* loss_rows, int64_t n_entropy,
+                      int32_t last_seq_len, float entropy_target, const float* entropy, float entropy_upstream, float* entropy_loss,
+                      float* d_entropy, void* stream) {
     if (rows <= 0 || cols <= 0 || d <= 0 || temperature <= 0.f || n_entropy < 0) return AECF_ERR_BAD_DIMS;
     if (row_offset < 0 || row_offset + rows > cols) return AECF_ERR_BAD_DIMS;
     if (!nce_gemm_supported(AECF_BF16, d, temperature)) return AECF_ERR_UNSUPPORTED;
-    if (!a || !b || !col_sums || !workspace || !loss_rows || !da || !db) return AECF_ERR_NULL_POINTER;
+    if (!a || !b || !col_sums || !workspace || !loss_rows) return AECF_ERR_NULL_POINTER;
     if (n_entropy > 0 && (!entropy || !entropy_loss)) return AECF_ERR_NULL_POINTER;
     if (workspace_bytes < nce_gemm_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
     const double max_ent = last_seq_len > 1 ? log((double)last_seq_len) : 0.0;       // ref :301-308
-    launch_nce_gemm_pass2(rows, cols, row_offset, d, 1.0f / temperature, coef, 1, a, b, col_sums, workspace, loss_rows, da, db,
-                          n_entropy > 0 ? entropy : nullptr, n_entropy, (float)(max_ent * (double)entropy_target), entropy_upstream,
-                          d_entropy, entropy_loss, (hipStream_t)stream);
+    launch_nce_gemm_loss(rows, cols, row_offset, d, 1.0f / temperature, 1, a, b, col_sums, workspace, loss_rows,
+                         n_entropy > 0 ? entropy : nullptr, n_entropy, (float)(max_ent * (double)entropy_target), entropy_upstream,
+                         d_entropy, entropy_loss, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_nce_sym_grads(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef, const void* a,
+                       const void* b, void* workspace, size_t workspace_bytes, const float* upstream, int32_t grad_dtype, void* da,
+                       void* db, void* stream) {
+    if (rows <= 0 || cols <= 0 || d <= 0 || temperature <= 0.f) return AECF_ERR_BAD_DIMS;
+    if (row_offset < 0 || row_offset + rows > cols) return AECF_ERR_BAD_DIMS;
+    if (!nce_gemm_supported(AECF_BF16, d, temperature)) return AECF_ERR_UNSUPPORTED;
+    if (grad_dtype != AECF_BF16 && grad_dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (!a || !b || !workspace || !da || !db) return AECF_ERR_NULL_POINTER;
+    if (workspace_bytes < nce_gemm_workspace_bytes(rows, cols, d)) return AECF_ERR_WORKSPACE;
+    launch_nce_gemm_grads(rows, cols, row_offset, d, 1.0f / temperature, coef, 1, a, b, workspace, upstream,
+                          grad_dtype == AECF_BF16 ? 1 : 0, da, db, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -930,8 +946,10 @@ int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, 
     if (!q || !k || !loss_rows || !dq || !dk || !workspace) return AECF_ERR_NULL_POINTER;
     if (nce_gemm_supported(dtype, d, temperature) && workspace_bytes >= nce_gemm_workspace_bytes(rows, cols, d)) {
         launch_nce_gemm_pass1(rows, cols, d, 1.0f / temperature, q, k, workspace, nullptr, (hipStream_t)stream);
-        launch_nce_gemm_pass2(rows, cols, row_offset, d, 1.0f / temperature, coef, 0, q, k, nullptr, workspace, loss_rows, dq, dk,
-                              nullptr, 0, 0.f, 0.f, nullptr, nullptr, (hipStream_t)stream);
+        launch_nce_gemm_loss(rows, cols, row_offset, d, 1.0f / temperature, 0, q, k, nullptr, workspace, loss_rows, nullptr, 0, 0.f,
+                             0.f, nullptr, nullptr, (hipStream_t)stream);
+        launch_nce_gemm_grads(rows, cols, row_offset, d, 1.0f / temperature, coef, 0, q, k, workspace, nullptr, 0, dq, dk,
+                              (hipStream_t)stream);
         return launch_status();
     }
     if (nce_flash_supported(dtype, d)) {         // streaming form: any rows / cols, workspace O(rows d)

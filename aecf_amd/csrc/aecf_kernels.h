@@ -219,10 +219,11 @@ bool nce_gemm_supported(int dtype, int d, float temperature);
 size_t nce_gemm_workspace_bytes(int64_t rows, int64_t cols, int d);
 void launch_nce_gemm_pass1(int64_t rows, int64_t cols, int d, float inv_temp, const void* a, const void* b, void* workspace,
                            float* col_sums, hipStream_t s);
-void launch_nce_gemm_pass2(int64_t rows, int64_t cols, int64_t row_offset, int d, float inv_temp, float coef, int sym, const void* a,
-                           const void* b, const float* col_sums, void* workspace, float* loss_rows, float* da, float* db,
-                           const float* ent, int64_t n_ent, float ent_target, float ent_upstream, float* d_ent, float* ent_loss,
-                           hipStream_t s);
+void launch_nce_gemm_loss(int64_t rows, int64_t cols, int64_t row_offset, int d, float inv_temp, int sym, const void* a,
+                          const void* b, const float* col_sums, void* workspace, float* loss_rows, const float* ent, int64_t n_ent,
+                          float ent_target, float ent_upstream, float* d_ent, float* ent_loss, hipStream_t s);
+void launch_nce_gemm_grads(int64_t rows, int64_t cols, int64_t row_offset, int d, float inv_temp, float coef, int sym, const void* a,
+                           const void* b, void* workspace, const float* upstream, int out_bf16, void* da, void* db, hipStream_t s);
 
 // ---------------- presence routing (aecf_route.hip) ----------------
 void launch_route_build(int64_t rows, const uint8_t* pa, const uint8_t* pb, int32_t* route, int32_t* slot, int32_t* index,

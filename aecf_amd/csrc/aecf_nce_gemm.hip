@@ -57,8 +57,9 @@ struct NceGemmArgs {
     float* rowsum_part;                 // [n_tiles][m_tiles 256]
     float* colsum_part;                 // [m_tiles][n_tiles 256]
     // EPI_OUT
-    float* out;                         // [splits][m_valid][ldo]
+    void* out;                          // [splits][m_valid][ldo] float32, or (out_bf16, no splits) bf16
     int64_t ldo, slab_stride;
+    int out_bf16;
 };
 
 #pragma clang diagnostic push
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(512, 2) void nce_gemm_kernel(NceGemmArgs p) {
         const int64_t gi0 = (int64_t)BT * mi + 128 * wm + r16;
         const int gj0 = BT * ni + 64 * wn + 4 * lg;
         if (EPI == EPI_OUT) {
-            float* o = p.out + (int64_t)split * p.slab_stride;
+            float* o = reinterpret_cast<float*>(p.out) + (int64_t)split * p.slab_stride;
+            unsigned short* ob = reinterpret_cast<unsigned short*>(p.out);
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) {
                 const int64_t i = gi0 + 16 * rt;
@@ -308,7 +310,12 @@ __global__ __launch_bounds__(512, 2) void nce_gemm_kernel(NceGemmArgs p) {
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
                         const int j = gj0 + 16 * ct;
-                        if (j < p.n_valid) *reinterpret_cast<f32x4*>(o + i * p.ldo + j) = acc[rt][ct];
+                        if (j < p.n_valid) {
+                            if (p.out_bf16)
+                                *reinterpret_cast<u32x2*>(ob + i * p.ldo + j) =
+                                    u32x2{pack_bf16x2(acc[rt][ct][0], acc[rt][ct][1]), pack_bf16x2(acc[rt][ct][2], acc[rt][ct][3])};
+                            else *reinterpret_cast<f32x4*>(o + i * p.ldo + j) = acc[rt][ct];
+                        }
                     }
                 }
             }
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(256) void nce_finalize_kernel(NceFinArgs p) {
 // small difference of O(1) terms (softmax weight minus one): it is formed from the float32 exponential, not from the bf16 one.
 __global__ __launch_bounds__(256) void nce_weights_kernel(unsigned short* e, int64_t e_tiles, int64_t m_tiles, const float* u,
                                                           const float* v, const float* ediag, int64_t rows, int64_t row_offset,
-                                                          float ct, float npos) {
+                                                          float ct, float npos, const float* upstream) {
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;         // 16-byte chunk: 2048 per tile, 8 per tile row
     if (id >= m_tiles * e_tiles * 2048) return;
     const int64_t tile = id >> 11;
@@ -483,6 +490,7 @@ __global__ __launch_bounds__(256) void nce_weights_kernel(unsigned short* e, int
     Tr<BF16>::unpack(raw, x);
     const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     const int64_t jp = (i < rows) ? row_offset + i - j0 : -1;
+    if (upstream) ct *= upstream[0];                           // d loss / d (this call's term): a device scalar, no host read
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         float wv = x[k] * (ui + vv[k]);
@@ -492,8 +500,9 @@ __global__ __launch_bounds__(256) void nce_weights_kernel(unsigned short* e, int
     *ptr = Tr<BF16>::pack(x);
 }
 
-// out[i] = sum_s slab[s][i], float4
-__global__ __launch_bounds__(256) void nce_slab_sum_kernel(const float* slabs, int splits, int64_t n4, int64_t stride, float* out) {
+// out[i] = sum_s slab[s][i], float4 (rounded once to bf16 when the caller wants the gradient in that dtype)
+__global__ __launch_bounds__(256) void nce_slab_sum_kernel(const float* slabs, int splits, int64_t n4, int64_t stride, void* out,
+                                                           int out_bf16) {
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= n4) return;
     f32x4 s = *reinterpret_cast<const f32x4*>(slabs + 4 * id);
@@ -501,7 +510,8 @@ __global__ __launch_bounds__(256) void nce_slab_sum_kernel(const float* slabs, i
         const f32x4 t = *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * stride + 4 * id);
         s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
     }
-    *reinterpret_cast<f32x4*>(out + 4 * id) = s;
+    if (out_bf16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + 4 * id) = u32x2{pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + 4 * id) = s;
 }
 
 template <int AM, int BM, int EPI, int MAP>
@@ -588,11 +598,10 @@ void launch_nce_gemm_pass1(int64_t rows, int64_t cols, int d, float inv_temp, co
                                                                                    rows, cols, w.l, col_sums ? col_sums : w.c_local);
 }
 
-// pass 2: weights in place, both gradient products, loss rows (col_sums: all ranks' sums when sym; NULL = pass 1's own)
-void launch_nce_gemm_pass2(int64_t rows, int64_t cols, int64_t row_offset, int d, float inv_temp, float coef, int sym, const void* a,
-                           const void* b, const float* col_sums, void* workspace, float* loss_rows, float* da, float* db,
-                           const float* ent, int64_t n_ent, float ent_target, float ent_upstream, float* d_ent, float* ent_loss,
-                           hipStream_t s) {
+// normalisers + loss rows (col_sums: all ranks' sums when sym; NULL = pass 1's own) [+ the entropy regulariser riding along]
+void launch_nce_gemm_loss(int64_t rows, int64_t cols, int64_t row_offset, int d, float inv_temp, int sym, const void* a,
+                          const void* b, const float* col_sums, void* workspace, float* loss_rows, const float* ent, int64_t n_ent,
+                          float ent_target, float ent_upstream, float* d_ent, float* ent_loss, hipStream_t s) {
     const NceWs w = carve(workspace, rows, cols, d);
     const int64_t Rp = up256(rows), Cp = up256(cols);
     NceFinArgs f = {};
@@ -602,9 +611,17 @@ void launch_nce_gemm_pass2(int64_t rows, int64_t cols, int64_t row_offset, int d
     f.ent = ent; f.d_ent = d_ent; f.ent_loss = ent_loss; f.n_ent = ent ? n_ent : 0; f.ent_target = ent_target;
     f.ent_scale = n_ent > 0 ? 2.0f * ent_upstream / (float)n_ent : 0.f;
     nce_finalize_kernel<<<dim3((unsigned)((Rp + 3) / 4)), dim3(256), 0, s>>>(f);
+}
+
+// gradients: weights in place over E (scaled by the device scalar `upstream` when given), da = W b, db = W^T a; outputs float32
+// or -- one rounding of the float32 sums -- bf16.  launch_nce_gemm_loss must have run on this workspace.
+void launch_nce_gemm_grads(int64_t rows, int64_t cols, int64_t row_offset, int d, float inv_temp, float coef, int sym, const void* a,
+                           const void* b, void* workspace, const float* upstream, int out_bf16, void* da, void* db, hipStream_t s) {
+    const NceWs w = carve(workspace, rows, cols, d);
+    const int64_t Rp = up256(rows), Cp = up256(cols);
     const int64_t chunks = Rp * (Cp / 8);
     nce_weights_kernel<<<dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s>>>(w.e, Cp / 64, Rp / BT, w.u, w.v, w.ediag, rows, row_offset,
-                                                                                    coef * inv_temp, sym ? 2.0f : 1.0f);
+                                                                                    coef * inv_temp, sym ? 2.0f : 1.0f, upstream);
     const int n_tiles_d = (d + BT - 1) / BT;
     {   // da = W b: m = local rows, n = d, K = keys
         NceGemmArgs g = {};
@@ -615,13 +632,14 @@ void launch_nce_gemm_pass2(int64_t rows, int64_t cols, int64_t row_offset, int d
         g.splits = da_splits(Rp, Cp, d);
         g.steps_per_split = (g.k_steps + g.splits - 1) / g.splits;
         g.m_valid = (int)rows; g.n_valid = d;
-        g.out = g.splits > 1 ? w.slabs : da; g.ldo = d; g.slab_stride = rows * (int64_t)d;
+        g.out = g.splits > 1 ? (void*)w.slabs : da; g.ldo = d; g.slab_stride = rows * (int64_t)d;
+        g.out_bf16 = g.splits > 1 ? 0 : out_bf16;
         const unsigned int units = (unsigned)(g.m_tiles * g.splits);
         if (g.splits == 8) launch_gemm<OP_ROW, OP_COL, EPI_OUT, MAP_SPLITX>(g, 8u * g.m_tiles * g.n_tiles, s);
         else launch_gemm<OP_ROW, OP_COL, EPI_OUT, MAP_UNITS>(g, ((units + 7) / 8) * 8 * g.n_tiles, s);
         if (g.splits > 1) {
             const int64_t n4 = rows * (int64_t)d / 4;
-            nce_slab_sum_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(w.slabs, g.splits, n4, g.slab_stride, da);
+            nce_slab_sum_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(w.slabs, g.splits, n4, g.slab_stride, da, out_bf16);
         }
     }
     {   // db = W^T a: m = keys, n = d, K = local rows
@@ -631,7 +649,7 @@ void launch_nce_gemm_pass2(int64_t rows, int64_t cols, int64_t row_offset, int d
         g.m_tiles = (int)(Cp / BT); g.n_tiles = n_tiles_d; g.k_steps = (int)(Rp / 64);
         g.splits = 1; g.steps_per_split = g.k_steps;
         g.m_valid = (int)cols; g.n_valid = d;
-        g.out = db; g.ldo = d; g.slab_stride = 0;
+        g.out = db; g.ldo = d; g.slab_stride = 0; g.out_bf16 = out_bf16;
         const unsigned int units = (unsigned)g.m_tiles;
         launch_gemm<OP_COLB, OP_COL, EPI_OUT, MAP_UNITS>(g, ((units + 7) / 8) * 8 * g.n_tiles, s);
     }

@@ -87,11 +87,13 @@ class _NceDirection(torch.autograd.Function):
 
 
 class _NceSymmetric(torch.autograd.Function):
-    """aecf_nce_sym_pass1 / _pass2: BOTH directions of the symmetric InfoNCE from one block of logits (local rows of view a
+    """aecf_nce_sym_pass1 / _loss / _grads: BOTH directions of the symmetric InfoNCE from one block of logits (local rows of view a
     against the gathered rows of view b).  The column sums of the exponentials are the one thing ranks exchange (one
-    all-reduce of `cols` floats between the passes); the gradient on the gathered keys is this rank's share (the caller's
-    all-gather backward reduce-scatters it).  Optionally carries CurriculumMasking.entropy_loss (ref aecf/AECFLayer.py:285-314)
-    in the same call.  Returns (this rank's rows' share of the loss, entropy loss)."""
+    all-reduce of `cols` floats between pass 1 and the loss); the gradient on the gathered keys is this rank's share (the
+    caller's all-gather backward reduce-scatters it).  The forward runs the logits pass and the loss; the two gradient products
+    run in the backward, scaled on the device by the gradient that arrives there and written in the inputs' dtype (no float32
+    [cols, d] intermediate, no multiply / cast passes).  Optionally carries CurriculumMasking.entropy_loss (ref
+    aecf/AECFLayer.py:285-314) in the loss launch.  Returns (this rank's rows' share of the loss, entropy loss)."""
 
     @staticmethod
     def forward(ctx, a, b_all, entropy, row_offset, temperature, coef, group, last_seq_len, entropy_target):
@@ -110,29 +112,39 @@ class _NceSymmetric(torch.autograd.Function):
                                           _stream()), "aecf_nce_sym_pass1")
         if dp.world_info(group)[1] > 1:
             torch.distributed.all_reduce(col_sums, group=group)
-        loss_rows, da, db = torch.empty(rows, **f32), torch.empty(rows, d, **f32), torch.empty(cols, d, **f32)
+        loss_rows = torch.empty(rows, **f32)
         if entropy is not None:
             ent = entropy.detach().to(torch.float32).contiguous().reshape(-1)
             ent_loss, dent = torch.zeros(1, **f32), torch.empty(ent.numel(), **f32)
             n_ent, p_ent, p_el, p_de = ent.numel(), _ptr(ent), _ptr(ent_loss), _ptr(dent)
         else:
             ent_loss, dent, n_ent, p_ent, p_el, p_de = torch.zeros(1, **f32), None, 0, None, None, None
-        _lib.check(lib.aecf_nce_sym_pass2(rows, cols, row_offset, d, temperature, coef, _ptr(ac), _ptr(bc), _ptr(col_sums),
-                                          _ptr(ws), ws_bytes, _ptr(loss_rows), _ptr(da), _ptr(db), n_ent, last_seq_len,
-                                          entropy_target, p_ent, 1.0, p_el, p_de, _stream()), "aecf_nce_sym_pass2")
-        ctx.save_for_backward(da, db, *([dent] if dent is not None else []))
-        ctx.meta = (a.dtype, b_all.dtype, None if entropy is None else (entropy.dtype, entropy.shape))
+        _lib.check(lib.aecf_nce_sym_loss(rows, cols, row_offset, d, temperature, _ptr(ac), _ptr(bc), _ptr(col_sums), _ptr(ws),
+                                         ws_bytes, _ptr(loss_rows), n_ent, last_seq_len, entropy_target, p_ent, 1.0, p_el, p_de,
+                                         _stream()), "aecf_nce_sym_loss")
+        ctx.save_for_backward(ac, bc, ws, *([dent] if dent is not None else []))
+        ctx.meta = (a.dtype, b_all.dtype, None if entropy is None else (entropy.dtype, entropy.shape),
+                    (rows, cols, int(row_offset), d, float(temperature), float(coef), ws_bytes))
         return loss_rows.sum() * coef, ent_loss.reshape(())
 
     @staticmethod
     def backward(ctx, d_nce, d_ent):
-        da, db = ctx.saved_tensors[:2]
-        ad, bd, em = ctx.meta
-        g = d_nce.to(torch.float32)
+        lib = _lib.load()
+        ac, bc, ws = ctx.saved_tensors[:3]
+        ad, bd, em, (rows, cols, row_offset, d, temperature, coef, ws_bytes) = ctx.meta
+        if getattr(ctx, "_spent", False):
+            raise RuntimeError("aecf_amd: the symmetric InfoNCE backward runs once per forward (it consumes the stored logits)")
+        ctx._spent = True
+        gdt = torch.bfloat16 if (ad == torch.bfloat16 and bd == torch.bfloat16) else torch.float32
+        da = torch.empty(rows, d, dtype=gdt, device=ac.device)
+        db = torch.empty(cols, d, dtype=gdt, device=ac.device)
+        up = d_nce.detach().to(torch.float32).reshape(1).contiguous()
+        _lib.check(lib.aecf_nce_sym_grads(rows, cols, row_offset, d, temperature, coef, _ptr(ac), _ptr(bc), _ptr(ws), ws_bytes,
+                                          _ptr(up), _DTYPES[gdt], _ptr(da), _ptr(db), _stream()), "aecf_nce_sym_grads")
         g_ent = None
         if em is not None:
-            g_ent = (ctx.saved_tensors[2] * d_ent.to(torch.float32)).reshape(em[1]).to(em[0])
-        return (da * g).to(ad), (db * g).to(bd), g_ent, None, None, None, None, None, None
+            g_ent = (ctx.saved_tensors[3] * d_ent.to(torch.float32)).reshape(em[1]).to(em[0])
+        return da.to(ad), db.to(bd), g_ent, None, None, None, None, None, None
 
 
 def _sym_supported(z: torch.Tensor, temperature: float, cols: Optional[int] = None) -> bool:
@@ -209,7 +221,7 @@ def gathered_contrastive_entropy_loss(za: torch.Tensor, nb_all: torch.Tensor, ro
     """The loss side of a data-parallel step in ONE operator: this rank's rows ``za`` [b_local, d] (bf16, not yet normalised)
     against the unit-norm rows of the other view from EVERY rank ``nb_all`` [b_all, d] (``dp.all_gather_rows(l2_normalize(zb))``:
     its backward reduce-scatters the share of the gradient this call returns), positives at ``row_offset + i``; both InfoNCE
-    directions from the one block of logits (``aecf_nce_sym_pass1/2``; the column sums are all-reduced over ``group`` between
+    directions from the one block of logits (``aecf_nce_sym_pass1`` / ``_loss`` / ``_grads``; the column sums are all-reduced over ``group`` between
     the passes) plus ``entropy_weight * masking.entropy_loss(entropy)`` riding in the same call.  Returns this rank's share of
     ``contrastive_weight * L_nce`` (coef = 0.5 / b_all) plus the entropy term."""
     _require_device(za, "za")

@@ -372,19 +372,26 @@ int aecf_loss_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d,
  * E = exp((a.b - 1)/T) are the one quantity ranks exchange:
  *   pass1: E (bf16, workspace), its row sums (workspace), and THIS rank's column sums col_sums [cols] (float32)
  *   caller: all-reduce (sum) of col_sums over the ranks (nothing to do on one rank)
- *   pass2: loss_rows[i] = both terms of local row i (float32 [rows]); da = dL/da [rows,d]; db = this rank's share of dL/db
- *          [cols,d] (the sum over ranks is the caller's reduce-scatter); optionally CurriculumMasking.entropy_loss forward +
- *          backward riding in one of its launches (arguments as aecf_loss_fwd_bwd; n_entropy == 0: off).
+ *   loss:  loss_rows[i] = both terms of local row i (float32 [rows]) from the summed column sums; optionally
+ *          CurriculumMasking.entropy_loss forward + backward riding in the same launch (arguments as aecf_loss_fwd_bwd;
+ *          n_entropy == 0: off).  Also prepares the normalisers the gradients need (kept in the workspace).
+ *   grads: da = dL/da [rows,d]; db = this rank's share of dL/db [cols,d] (the sum over ranks is the caller's reduce-scatter), both
+ *          multiplied by upstream[0] when `upstream` (a DEVICE float32 scalar: the gradient arriving at this term; no host read)
+ *          is given, in float32 or -- one rounding of the float32 sums -- bf16 (grad_dtype).  May run long after `loss` (an
+ *          autograd backward): the workspace must be left alone in between; it overwrites E with the softmax weights, so it
+ *          runs once per pass1.
  * 6 rows cols d MFMA flops for both directions (2 for the logits, 2 + 2 for the gradient products through transposed LDS
  * reads) against 16 rows cols d for two calls of the streaming form.  Workspace: rows x cols bf16 + O(rows + cols) floats. */
 size_t aecf_nce_sym_workspace_bytes(int64_t rows, int64_t cols, int32_t d);
 int aecf_nce_sym_pass1(int64_t rows, int64_t cols, int32_t d, float temperature, const void* a, const void* b,
                        void* workspace, size_t workspace_bytes, float* col_sums, void* stream);
-int aecf_nce_sym_pass2(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef,
-                       const void* a, const void* b, const float* col_sums, void* workspace, size_t workspace_bytes,
-                       float* loss_rows, float* da, float* db, int64_t n_entropy, int32_t last_seq_len,
-                       float entropy_target, const float* entropy, float entropy_upstream, float* entropy_loss,
-                       float* d_entropy, void* stream);
+int aecf_nce_sym_loss(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, const void* a,
+                      const void* b, const float* col_sums, void* workspace, size_t workspace_bytes, float* loss_rows,
+                      int64_t n_entropy, int32_t last_seq_len, float entropy_target, const float* entropy,
+                      float entropy_upstream, float* entropy_loss, float* d_entropy, void* stream);
+int aecf_nce_sym_grads(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, float temperature, float coef,
+                       const void* a, const void* b, void* workspace, size_t workspace_bytes, const float* upstream,
+                       int32_t grad_dtype, void* da, void* db, void* stream);
 
 #ifdef __cplusplus
 }

@@ -69,8 +69,10 @@ def _run_sharded(a, b, T, bounds):
     for lo, hi, al, ws, ws_bytes in shards:
         rows = hi - lo
         lr, da_s, db_s = torch.empty(rows, **f32), torch.empty(rows, d, **f32), torch.empty(n, d, **f32)
-        _lib.check(lib.aecf_nce_sym_pass2(rows, n, lo, d, T, coef, _ptr(al), _ptr(b), _ptr(col_total), _ptr(ws), ws_bytes,
-                                          _ptr(lr), _ptr(da_s), _ptr(db_s), 0, 2, 0.0, None, 1.0, None, None, _stream()), "pass2")
+        _lib.check(lib.aecf_nce_sym_loss(rows, n, lo, d, T, _ptr(al), _ptr(b), _ptr(col_total), _ptr(ws), ws_bytes, _ptr(lr), 0, 2,
+                                         0.0, None, 1.0, None, None, _stream()), "loss")
+        _lib.check(lib.aecf_nce_sym_grads(rows, n, lo, d, T, coef, _ptr(al), _ptr(b), _ptr(ws), ws_bytes, None, _lib.AECF_F32,
+                                          _ptr(da_s), _ptr(db_s), _stream()), "grads")
         loss_rows[lo:hi], da[lo:hi] = lr, da_s
         db += db_s
     return loss_rows, da, db
@@ -159,8 +161,10 @@ def test_symmetric_nce_config3_size():
     # pass 2 with this block's own column sums standing in for the all-reduced ones: weights E (1/l_i + 1/c_j)
     coef = 0.5 / cols
     lr, da, db = torch.empty(rows, **f32), torch.empty(rows, d, **f32), torch.empty(cols, d, **f32)
-    _lib.check(lib.aecf_nce_sym_pass2(rows, cols, off, d, T, coef, _ptr(al), _ptr(b), _ptr(cs), _ptr(ws), ws_bytes, _ptr(lr),
-                                      _ptr(da), _ptr(db), 0, 2, 0.0, None, 1.0, None, None, _stream()), "pass2")
+    _lib.check(lib.aecf_nce_sym_loss(rows, cols, off, d, T, _ptr(al), _ptr(b), _ptr(cs), _ptr(ws), ws_bytes, _ptr(lr), 0, 2, 0.0,
+                                     None, 1.0, None, None, _stream()), "loss")
+    _lib.check(lib.aecf_nce_sym_grads(rows, cols, off, d, T, coef, _ptr(al), _ptr(b), _ptr(ws), ws_bytes, None, _lib.AECF_F32,
+                                      _ptr(da), _ptr(db), _stream()), "grads")
     col_lse = (torch.log(want_cs) + 1.0 / T).float()
     want_da, want_db = torch.zeros(rows, d, **f32), torch.zeros(cols, d, **f32)
     bf = b.float()
@@ -175,3 +179,33 @@ def test_symmetric_nce_config3_size():
     assert rel_err(da, want_da) < 1.5e-2 and rel_err(db, want_db) < 1.5e-2
     diag = (al.float() * bf[off:off + rows]).sum(1) / T
     assert rel_err(lr, (row_lse - diag) + (col_lse[off:off + rows] - diag)) < 1e-3
+
+
+def test_symmetric_nce_gradients_in_bf16_scaled_on_the_device():
+    """aecf_nce_sym_grads with an upstream scalar in device memory and bf16 outputs (what the autograd backward asks for)
+    equals the float32 gradients times that scalar, rounded once."""
+    from aecf_amd import _lib
+    from aecf_amd.layer import _ptr, _stream
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    n, d, T = 777, 256, 0.07
+    a, b = _inputs(n, d, 21, dev)
+    coef = 0.5 / n
+    f32 = dict(dtype=torch.float32, device=dev)
+    outs = []
+    for gdt, up in ((torch.float32, None), (torch.bfloat16, torch.tensor([0.375], **f32))):
+        ws_bytes = lib.aecf_nce_sym_workspace_bytes(n, n, d)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        cs, lr = torch.empty(n, **f32), torch.empty(n, **f32)
+        da, db = torch.empty(n, d, dtype=gdt, device=dev), torch.empty(n, d, dtype=gdt, device=dev)
+        _lib.check(lib.aecf_nce_sym_pass1(n, n, d, T, _ptr(a), _ptr(b), _ptr(ws), ws_bytes, _ptr(cs), _stream()), "pass1")
+        _lib.check(lib.aecf_nce_sym_loss(n, n, 0, d, T, _ptr(a), _ptr(b), _ptr(cs), _ptr(ws), ws_bytes, _ptr(lr), 0, 2, 0.0, None,
+                                         1.0, None, None, _stream()), "loss")
+        _lib.check(lib.aecf_nce_sym_grads(n, n, 0, d, T, coef, _ptr(a), _ptr(b), _ptr(ws), ws_bytes, None if up is None else _ptr(up),
+                                          _lib.AECF_BF16 if gdt == torch.bfloat16 else _lib.AECF_F32, _ptr(da), _ptr(db), _stream()),
+                   "grads")
+        outs.append((da.float(), db.float()))
+    # the weights are rounded to bf16 AFTER the scaling (another draw of the same rounding: each run sits within 1.5e-2 of
+    # float32 math, see test_symmetric_nce_matches_float32_reference) and the outputs carry one bf16 rounding
+    e_a, e_b = rel_err(outs[1][0], 0.375 * outs[0][0]), rel_err(outs[1][1], 0.375 * outs[0][1])
+    assert e_a < 2e-2 and e_b < 2e-2, (e_a, e_b)

@@ -34,8 +34,10 @@ def main():
     print("  bad E entries", bad.shape[0], bad[:8].tolist())
     print("col sums rel err", rel(cs, Eref.sum(0)))
     lr, da, db = torch.empty(rows, **f32), torch.empty(rows, d, **f32), torch.empty(cols, d, **f32)
-    _lib.check(lib.aecf_nce_sym_pass2(rows, cols, off, d, T, coef, _ptr(a), _ptr(b), _ptr(cs), _ptr(ws), ws_bytes, _ptr(lr), _ptr(da),
-                                      _ptr(db), 0, 2, 0.0, None, 1.0, None, None, _stream()), "p2")
+    _lib.check(lib.aecf_nce_sym_loss(rows, cols, off, d, T, _ptr(a), _ptr(b), _ptr(cs), _ptr(ws), ws_bytes, _ptr(lr), 0, 2, 0.0, None,
+                                     1.0, None, None, _stream()), "loss")
+    _lib.check(lib.aecf_nce_sym_grads(rows, cols, off, d, T, coef, _ptr(a), _ptr(b), _ptr(ws), ws_bytes, None, _lib.AECF_F32, _ptr(da),
+                                      _ptr(db), _stream()), "grads")
     torch.cuda.synchronize()
     W = ws[:Rp * Cp * 2].view(torch.bfloat16).view(Rp // 256, Cp // 64, 256, 64).permute(0, 2, 1, 3).reshape(Rp, Cp).clone().float()
     l, c = Eref.sum(1), Eref.sum(0)

@@ -25,6 +25,7 @@ def main():
     f32 = dict(dtype=torch.float32, device=dev)
     loss_rows, dq, dk = torch.empty(rows, **f32), torch.empty(rows, d, **f32), torch.empty(cols, d, **f32)
     cs = torch.empty(cols, **f32)
+    dq16, dk16 = torch.empty(rows, d, dtype=torch.bfloat16, device=dev), torch.empty(cols, d, dtype=torch.bfloat16, device=dev)
     if mode == "stream":
         ws_bytes = lib.aecf_nce_stream_workspace_bytes(rows, cols, d, _lib.AECF_BF16)
     elif mode == "gemm":
@@ -36,9 +37,10 @@ def main():
     def call():
         if mode == "sym":
             _lib.check(lib.aecf_nce_sym_pass1(rows, cols, d, 0.07, _ptr(q), _ptr(k), _ptr(ws), ws_bytes, _ptr(cs), _stream()), "pass1")
-            _lib.check(lib.aecf_nce_sym_pass2(rows, cols, 0, d, 0.07, 0.5 / cols, _ptr(q), _ptr(k), _ptr(cs), _ptr(ws), ws_bytes,
-                                              _ptr(loss_rows), _ptr(dq), _ptr(dk), 0, 2, 0.0, None, 1.0, None, None, _stream()),
-                       "pass2")
+            _lib.check(lib.aecf_nce_sym_loss(rows, cols, 0, d, 0.07, _ptr(q), _ptr(k), _ptr(cs), _ptr(ws), ws_bytes, _ptr(loss_rows),
+                                             0, 2, 0.0, None, 1.0, None, None, _stream()), "loss")
+            _lib.check(lib.aecf_nce_sym_grads(rows, cols, 0, d, 0.07, 0.5 / cols, _ptr(q), _ptr(k), _ptr(ws), ws_bytes, None,
+                                              _lib.AECF_BF16, _ptr(dq16), _ptr(dk16), _stream()), "grads")
         else:
             _lib.check(lib.aecf_nce_fwd_bwd(rows, cols, 0, d, _lib.AECF_BF16, 0.07, 0.5 / cols, _ptr(q), _ptr(k),
                                             _ptr(loss_rows), _ptr(dq), _ptr(dk), _ptr(ws), ws_bytes, _stream()),
