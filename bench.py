@@ -431,7 +431,8 @@ def main():
     params = [query] + list(pool.parameters())
     if world > 1:
         dp.broadcast_parameters(params)      # replicas start identical whatever the ranks' construction RNG did
-        dp.probe_avg_support(params[0].dtype, device)
+        # (no dp.probe_avg_support here: the step uses divide + ReduceOp.SUM, which every backend takes; ReduceOp.AVG would
+        #  save one 1 M-element divide per step and its start-up probe is one more thing that has never run on real RCCL)
     # curriculum-mask uniforms: every rank draws the SAME global tensor (shared seed, own generator) and uses its rows
     ugen = torch.Generator(device=device).manual_seed(1234) if world > 1 else None
     overlap = dp.GradOverlap(params=params) if (world > 1 and args.overlap and not args.no_overlap) else None
