@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AECF_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
 LIB_PATH = os.environ.get("AECF_LIB_PATH") or os.path.join(_HERE, "lib", "libaecf_hip.so")
 
-AECF_ABI_VERSION = 6
+AECF_ABI_VERSION = 7
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_PRECISE = 1
@@ -53,6 +53,7 @@ class PoolFwdArgs(Structure):
         ("info_attn_w", c_void_p), ("info_masked_w", c_void_p), ("info_entropy", c_void_p),
         ("info_mask_rate", c_void_p), ("saved_prep", c_void_p),
         ("info_target_entropy", c_void_p), ("target_entropy_value", c_float), ("flags", c_int32),
+        ("ent_loss_partial", c_void_p),
     ]
 
 
@@ -109,6 +110,7 @@ _SYMBOLS = [
     ("aecf_curriculum_mask_backward", c_int,
      [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_entropy_loss_workspace_bytes", c_size_t, [c_int64]),
+    ("aecf_entropy_loss_from_partials", c_int, [c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     ("aecf_entropy_loss_fwd_bwd", c_int,
      [c_int64, c_int32, c_int32, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_sdpa_forward", c_int,

@@ -308,6 +308,10 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
         v.c = a->saved_o;                                  // kept only when the caller wants it (backward)
         mark(ev, 2, s);
         launch_row_fwd(g, v, yo, s);
+        if (d->mask_mode == 1 && a->ent_loss_partial) {
+            if (a->info_entropy) launch_entropy_partials(d->dtype, d->batch, a->target_entropy_value, a->info_entropy, a->ent_loss_partial, s);
+            else if (a->entropy) launch_entropy_partials(AECF_F32, d->batch, a->target_entropy_value, a->entropy, a->ent_loss_partial, s);
+        }
         mark(ev, 3, s);
         mark(ev, 4, s);
         return launch_status();
@@ -319,10 +323,18 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
         v.g_ahi = a_hi; v.g_alo = a_lo; v.g_kpm = a->key_padding_mask;
         if (!gemm_ws_supported(v)) { fuse_gate = false; v.g_ahi = v.g_alo = nullptr; v.g_kpm = nullptr; }
     }
-    if (!fuse_gate) launch_gate_fwd(d->dtype, g, s);
+    // entropy-regulariser partial sums (optional): by the statistics kernel where it runs, else by one small launch behind the
+    // kernel that wrote the entropies (the caller may rely on them either way)
+    float* ent_partial = (d->mask_mode == 1 && !precise) ? a->ent_loss_partial : nullptr;
+    auto partials_after = [&]() {
+        if (!ent_partial) return;
+        if (a->info_entropy) launch_entropy_partials(d->dtype, d->batch, a->target_entropy_value, a->info_entropy, ent_partial, s);
+        else if (a->entropy) launch_entropy_partials(AECF_F32, d->batch, a->target_entropy_value, a->entropy, ent_partial, s);
+    };
+    if (!fuse_gate) { launch_gate_fwd(d->dtype, g, s); partials_after(); }
     mark(ev, 2, s);
     launch_gemm_nt(d->dtype, v, s);
-    if (fuse_gate) launch_gate_stats(d->dtype, g, s);
+    if (fuse_gate) { g.ent_partial = ent_partial; launch_gate_stats(d->dtype, g, s); }
     mark(ev, 3, s);
 
     GemmNtArgs y;
@@ -720,7 +732,8 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
     hipStream_t user = (hipStream_t)stream;
     if (d && a && !a->stage_events && !(a->flags & AECF_PRECISE) && graphs_enabled(d)) {   // (stage events / precise: plain launches)
         const GraphKey key{0, 0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
-                           (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->key_padding_mask ? 4 : 0)};
+                           (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->key_padding_mask ? 4 : 0) |
+                               (a->ent_loss_partial ? 8 : 0)};
         int status = AECF_OK;
         if (run_as_graph(key, user, [&](hipStream_t s) { return pool_forward_on(d, a, s); }, &status)) return status;
     }
@@ -792,6 +805,14 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
     if (S > 64 || T > 64 || (dtype != AECF_BF16 && dtype != AECF_F32)) return AECF_ERR_UNSUPPORTED;
     if (!q || !k || !v || !probs || !dout || !dq || !dk || !dv) return AECF_ERR_NULL_POINTER;
     launch_sdpa_bwd(dtype, B, S, T, E, scale, q, k, v, probs, dout, dq, dk, dv, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_entropy_loss_from_partials(int64_t n, int32_t dtype, const float* partial, void* loss, void* stream) {
+    if (n <= 0) return AECF_ERR_BAD_DIMS;
+    if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (!partial || !loss) return AECF_ERR_NULL_POINTER;
+    launch_entropy_from_partials(dtype, n, partial, loss, (hipStream_t)stream);
     return launch_status();
 }
 

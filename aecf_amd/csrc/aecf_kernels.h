@@ -50,6 +50,7 @@ struct GateArgs {
     void* i_mask_rate;
     void* i_target = nullptr; // [B] activation dtype filled with target_value (info['target_entropy']) or null
     float target_value = 0.f;
+    float* ent_partial = nullptr;   // [(B + 255) / 256] sums of (nan_to_num(H) - target_value)^2 per 256 rows, or null (gate_stats only)
     int64_t B;
     int M, E, H;
     MaskCfg mask;
@@ -186,6 +187,9 @@ void launch_mask_fwd(int64_t rows, int L, const MaskCfg& cfg, const float* w, co
                      float* entropy, float* mask_rate, uint8_t* bits, hipStream_t s);
 void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, const float* w, const uint8_t* bits,
                      const float* d_masked, const float* d_entropy, float* d_w, hipStream_t s);
+// partial[i] = sum over rows 256 i .. of (nan_to_num(H) - target)^2 (one block per 256 rows); loss = max(sum partial, 0) / n
+void launch_entropy_partials(int dtype, int64_t n, float target, const void* entropy, float* partial, hipStream_t s);
+void launch_entropy_from_partials(int dtype, int64_t n, const float* partial, void* loss, hipStream_t s);
 void launch_entropy_loss(int dtype, int64_t n, float target, const void* entropy, float upstream, void* loss,
                          float* d_entropy, float* partial, hipStream_t s);
 void launch_sdpa_fwd(int dtype, int64_t B, int S, int T, int E, float scale, const void* q, const void* k, const void* v,

@@ -354,6 +354,20 @@ __global__ __launch_bounds__(1024) void entropy_loss_single_kernel(int64_t n, fl
     }
 }
 
+void launch_entropy_partials(int dtype, int64_t n, float target, const void* entropy, float* partial, hipStream_t s) {
+    const int nblk = (int)((n + 255) / 256);                // (one block per 256 rows: the partition gate_stats uses)
+    if (dtype == 0)
+        entropy_loss_partial_kernel<BF16><<<dim3(nblk), dim3(256), 0, s>>>(n, target, (const unsigned short*)entropy, 0.f, nullptr, partial);
+    else
+        entropy_loss_partial_kernel<F32><<<dim3(nblk), dim3(256), 0, s>>>(n, target, (const float*)entropy, 0.f, nullptr, partial);
+}
+
+void launch_entropy_from_partials(int dtype, int64_t n, const float* partial, void* loss, hipStream_t s) {
+    const int nblk = (int)((n + 255) / 256);
+    if (dtype == 0) entropy_loss_final_kernel<BF16><<<dim3(1), dim3(256), 0, s>>>(nblk, 1.0f / (float)n, partial, (unsigned short*)loss);
+    else entropy_loss_final_kernel<F32><<<dim3(1), dim3(256), 0, s>>>(nblk, 1.0f / (float)n, partial, (float*)loss);
+}
+
 void launch_entropy_loss(int dtype, int64_t n, float target, const void* entropy, float upstream, void* loss,
                          float* d_entropy, float* partial, hipStream_t s) {
     if (n <= 8192) {       // (one block: measured 31 us at 65536 rows against 4.6 + 4.3 us for the two-kernel form below)

@@ -390,42 +390,56 @@ template <typename T, int M_>
 __global__ __launch_bounds__(256) void gate_stats_kernel(GateArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
+    __shared__ float red[4];
     const int64_t bs = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (bs >= p.B) return;
-    const int H = p.H;
-    float wsel[M_];
+    float sq = 0.f;                                              // this row's term of the entropy regulariser
+    if (bs < p.B) {
+        const int H = p.H;
+        float wsel[M_];
 #pragma unroll
-    for (int m = 0; m < M_; ++m) wsel[m] = 0.f;
-    for (int h = 0; h < H; ++h)
+        for (int m = 0; m < M_; ++m) wsel[m] = 0.f;
+        for (int h = 0; h < H; ++h)
 #pragma unroll
-        for (int m = 0; m < M_; ++m) wsel[m] += p.probs[(bs * H + h) * M_ + m];
-    const float invH = 1.0f / (float)H;
+            for (int m = 0; m < M_; ++m) wsel[m] += p.probs[(bs * H + h) * M_ + m];
+        const float invH = 1.0f / (float)H;
 #pragma unroll
-    for (int m = 0; m < M_; ++m) {
-        wsel[m] *= invH;
-        p.attn_w[bs * M_ + m] = wsel[m];
-        if (p.i_attn_w) reinterpret_cast<elem*>(p.i_attn_w)[bs * M_ + m] = X::from_f32(wsel[m]);
+        for (int m = 0; m < M_; ++m) {
+            wsel[m] *= invH;
+            p.attn_w[bs * M_ + m] = wsel[m];
+            if (p.i_attn_w) reinterpret_cast<elem*>(p.i_attn_w)[bs * M_ + m] = X::from_f32(wsel[m]);
+        }
+        if (p.mask.mode != 0) {
+            float w[M_], u[M_], mk[M_];
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                w[m] = wsel[m];
+                u[m] = (p.mask.mode == 1 && p.uniforms) ? p.uniforms[bs * M_ + m] : 0.f;
+            }
+            float ent, rate;
+            unsigned int bits;
+            curriculum_row<M_>(p.mask, M_, w, u, mk, ent, rate, bits);
+#pragma unroll
+            for (int m = 0; m < M_; ++m) {
+                if (p.masked_w) p.masked_w[bs * M_ + m] = mk[m];
+                if (p.i_masked_w) reinterpret_cast<elem*>(p.i_masked_w)[bs * M_ + m] = X::from_f32(mk[m]);
+            }
+            if (p.entropy) p.entropy[bs] = ent;
+            if (p.mask_rate) p.mask_rate[bs] = rate;
+            if (p.i_entropy) reinterpret_cast<elem*>(p.i_entropy)[bs] = X::from_f32(ent);
+            if (p.i_mask_rate) reinterpret_cast<elem*>(p.i_mask_rate)[bs] = X::from_f32(rate);
+            if (p.i_target) reinterpret_cast<elem*>(p.i_target)[bs] = X::from_f32(p.target_value);
+            // CurriculumMasking.entropy_loss (ref :285-314) reads the entropy as the info tensor holds it: its nan_to_num,
+            // the difference to the target and the square, summed per block here (the final launch adds the blocks)
+            float hv = p.i_entropy ? X::to_f32(X::from_f32(ent)) : ent;
+            hv = (hv != hv) ? 0.f : (isinf(hv) ? (hv > 0.f ? 1.f : 0.f) : hv);
+            sq = (hv - p.target_value) * (hv - p.target_value);
+        }
     }
-    if (p.mask.mode != 0) {
-        float w[M_], u[M_], mk[M_];
-#pragma unroll
-        for (int m = 0; m < M_; ++m) {
-            w[m] = wsel[m];
-            u[m] = (p.mask.mode == 1 && p.uniforms) ? p.uniforms[bs * M_ + m] : 0.f;
-        }
-        float ent, rate;
-        unsigned int bits;
-        curriculum_row<M_>(p.mask, M_, w, u, mk, ent, rate, bits);
-#pragma unroll
-        for (int m = 0; m < M_; ++m) {
-            if (p.masked_w) p.masked_w[bs * M_ + m] = mk[m];
-            if (p.i_masked_w) reinterpret_cast<elem*>(p.i_masked_w)[bs * M_ + m] = X::from_f32(mk[m]);
-        }
-        if (p.entropy) p.entropy[bs] = ent;
-        if (p.mask_rate) p.mask_rate[bs] = rate;
-        if (p.i_entropy) reinterpret_cast<elem*>(p.i_entropy)[bs] = X::from_f32(ent);
-        if (p.i_mask_rate) reinterpret_cast<elem*>(p.i_mask_rate)[bs] = X::from_f32(rate);
-        if (p.i_target) reinterpret_cast<elem*>(p.i_target)[bs] = X::from_f32(p.target_value);
+    if (p.ent_partial) {                                         // (block-uniform)
+        sq = reduce_wave(sq);
+        if (lane_id() == 0) red[wave_id()] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) p.ent_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     }
 }
 

@@ -102,7 +102,7 @@ class _PoolFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, q, w_in, b_in, w_out, b_out, kpm, uniforms, num_heads, mask_mode, min_active,
-                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None, casts=None):
+                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None, casts=None, side=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)       # unused outputs arrive as None, not as zero tensors (fill + cast launches)
         B, M, E = x.shape
@@ -147,6 +147,12 @@ class _PoolFunction(torch.autograd.Function):
             i_attn_w = i_masked_w = i_entropy = i_mask_rate = None
         # info['target_entropy'] (ref :273), filled by the kernel that writes the other info tensors
         i_target = torch.empty(B, dtype=dt, device=dev) if (mask_mode == 1 and target_value is not None) else None
+        # partial sums of the entropy regulariser over this call's rows, left behind by the kernel that writes the entropies
+        # (training mode): CurriculumMasking.entropy_loss(info['entropy']) is then one small launch (side = a dict of the caller)
+        ent_partial = None
+        if side is not None and mask_mode == 1 and target_value is not None:
+            ent_partial = torch.empty((B + 255) // 256, dtype=torch.float32, device=dev)
+            side["ent_partial"] = (ent_partial, B, float(target_value))
         ws_bytes = fwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolFwdArgs(
@@ -155,7 +161,7 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(ws), ws_bytes,
             None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd),
             _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate), _ptr(saved_prep),
-            _ptr(i_target), 0.0 if target_value is None else float(target_value), 0)
+            _ptr(i_target), 0.0 if target_value is None else float(target_value), 0, _ptr(ent_partial))
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
         ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep)
         ctx.desc = desc
@@ -221,7 +227,7 @@ class _PoolFunction(torch.autograd.Function):
                 db_in.to(bid) if (ctx.has_bias[0] and needs[3]) else None,
                 dw_out.to(wod) if needs[4] else None,
                 db_out.to(bod) if (ctx.has_bias[1] and needs[5]) else None,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def precise_forward_backward(x: torch.Tensor, query: torch.Tensor, w_in: torch.Tensor, b_in: Optional[torch.Tensor],
@@ -503,6 +509,17 @@ class CurriculumMasking(nn.Module):
         """ref :285-314 -- MSE between entropy and log(L_last) * entropy_target."""
         _require_device(entropy, "entropy")
         seq_len = self._last_seq_len if hasattr(self, '_last_seq_len') else 2
+        tag = getattr(entropy, "_aecf_entropy_partials", None)
+        if tag is not None and not entropy.requires_grad and entropy.dtype in _DTYPES:
+            # info['entropy'] of a fused pool forward, untouched: the kernel that wrote it left the per-block sums of
+            # (nan_to_num(H) - target)^2 behind (aecf_pool_fwd_args.ent_loss_partial) -- one small launch adds them up
+            partial, n, target = tag
+            want = math.log(float(seq_len)) * self.entropy_target if seq_len > 1 else 0.0
+            if entropy.numel() == n and abs(want - target) <= 1e-6 * max(1.0, abs(want)):
+                loss = torch.empty(1, dtype=entropy.dtype, device=entropy.device)
+                _lib.check(_lib.load().aecf_entropy_loss_from_partials(n, _DTYPES[entropy.dtype], _ptr(partial), _ptr(loss),
+                                                                       _stream()), "aecf_entropy_loss_from_partials")
+                return loss.reshape(())
         return _EntropyLossFunction.apply(entropy, int(seq_len), float(self.entropy_target))
 
     def extra_repr(self) -> str:                                              # ref :316-319
@@ -689,11 +706,12 @@ class MultimodalAttentionPool(nn.Module):
                 mask_u = _draw_uniforms((batch_size, tgt_len, src_len), x.device, uniforms, generator)
         a = self.attention
         tgt_value = math.log(float(src_len)) * cm.entropy_target if mask_mode == 1 else None        # ref :273
+        side: Dict[str, Any] = {}
         y, attn_w, masked_w, entropy, mask_rate, tgt_entropy = _PoolFunction.apply(
             x, q_base, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, kpm, mask_u,
             self.num_heads, mask_mode, 1 if cm is None else int(cm.min_active),
             0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8,
-            False, tgt_value, self._activation_dtype_params(x.dtype) if a.in_proj_weight.dtype != x.dtype else None)
+            False, tgt_value, self._activation_dtype_params(x.dtype) if a.in_proj_weight.dtype != x.dtype else None, side)
 
         dt = x.dtype
         attn_output = y.unsqueeze(1) if self.batch_first else y.unsqueeze(0)          # [B,1,E] / [1,B,E]
@@ -708,6 +726,9 @@ class MultimodalAttentionPool(nn.Module):
             elif cm.training:
                 cm._last_seq_len = src_len                                           # ref :187
                 ent = entropy.to(dt).unsqueeze(1)
+                if "ent_partial" in side and ent.dtype == entropy.dtype:
+                    # this very tensor object carries the regulariser's partial sums (entropy_loss looks for them)
+                    ent._aecf_entropy_partials = side["ent_partial"]
                 mask_info = {
                     'entropy': ent,
                     'mask_rate': mask_rate.unsqueeze(1),                             # float32 (ref :275)

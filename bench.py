@@ -45,6 +45,8 @@ CONFIGS = {
     "c5": (16384, 4, 1024, 8, torch.bfloat16, 0.15),      # configs[4] per-GPU shard (B=131072 / 8)
     "c3": (8192, 2, 768, 8, torch.bfloat16, 0.15),
     "tiny": (4096, 3, 128, 4, torch.bfloat16, 0.15),
+    "d256": (65536, 3, 256, 4, torch.bfloat16, 0.15),     # a narrower embedding (the example model's pool width), headline batch
+    "d384": (65536, 3, 384, 6, torch.bfloat16, 0.15),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16

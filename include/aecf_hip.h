@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define AECF_ABI_VERSION 6
+#define AECF_ABI_VERSION 7
 
 typedef enum aecf_status {
     AECF_OK = 0,
@@ -126,6 +126,12 @@ typedef struct aecf_pool_fwd_args {
      * gradients) are then float32 buffers; workspace = aecf_pool_precise_workspace_bytes.  A verification mode (it moves
      * twice the bytes): what "outputs match within 1e-3 relative, bf16" is asserted on. */
     int32_t flags;
+    /* optional (mask_mode 1; ABI v7): partial sums of CurriculumMasking.entropy_loss over the rows of this call (ref
+     * aecf/AECFLayer.py:285-314), float32 [(B + 255) / 256]: entry i = sum over rows 256 i .. of (nan_to_num(H) - target)^2 with
+     * H = the entropy as the info tensor holds it and target = target_entropy_value.  Written by the kernel that writes the
+     * entropies, so that a later entropy_loss of exactly this tensor is ONE small launch (aecf_entropy_loss_from_partials)
+     * instead of a pass over the rows.  NULL = not wanted. */
+    float* ent_loss_partial;
 } aecf_pool_fwd_args;
 
 #define AECF_PRECISE 1
@@ -211,6 +217,8 @@ int aecf_curriculum_mask_backward(int64_t rows, int32_t L, int32_t mode, float e
  * loss[0] = mean((nan_to_num(H) - log(last_seq_len)*entropy_target)^2); d_entropy = dloss/dH * upstream.
  * partial: scratch of aecf_entropy_loss_workspace_bytes(n). */
 size_t aecf_entropy_loss_workspace_bytes(int64_t n);
+/* loss[0] (dtype) = max(sum of the (n + 255) / 256 partial sums aecf_pool_forward left in ent_loss_partial, 0) / n */
+int aecf_entropy_loss_from_partials(int64_t n, int32_t dtype, const float* partial, void* loss, void* stream);
 /* entropy [n] and loss [1] have element type dtype (the reference computes the loss in the dtype of
  * info['entropy']); the arithmetic and d_entropy [n] are float32. */
 int aecf_entropy_loss_fwd_bwd(int64_t n, int32_t dtype, int32_t last_seq_len, float entropy_target,

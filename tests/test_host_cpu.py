@@ -37,7 +37,7 @@ def test_header_symbols_are_exported(built_library):
 def test_struct_layout_matches_header():
     # include/aecf_hip.h: aecf_pool_desc = int64 + 6*int32 + 3*float = 44 -> padded to 48
     assert ctypes.sizeof(_lib.PoolDesc) == 48
-    assert ctypes.sizeof(_lib.PoolFwdArgs) == 26 * 8
+    assert ctypes.sizeof(_lib.PoolFwdArgs) == 27 * 8
     assert ctypes.sizeof(_lib.PoolBwdArgs) == 24 * 8
 
 

@@ -711,3 +711,31 @@ def test_parameter_gradients_share_one_allocation():
     before = [p.grad.clone() for p in params]
     dp.all_reduce_grads(params)                                  # world 1: a no-op
     assert all(torch.equal(a, p.grad) for a, p in zip(before, params))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,M,E,H", [(5000, 3, 512, 8), (700, 2, 768, 8), (300, 5, 128, 4)])
+def test_entropy_loss_from_the_forward_partial_sums(dtype, B, M, E, H):
+    """CurriculumMasking.entropy_loss (ref aecf/AECFLayer.py:285-314) on info['entropy'] of a training-mode pool forward is
+    one small launch over the partial sums the forward left behind (aecf_pool_fwd_args.ent_loss_partial): equal to the
+    stand-alone operator on a copy of the tensor (which carries no partial sums), on the fused-statistics path (d = 512),
+    the gate-kernel path and the general shapes."""
+    import aecf_amd
+    dev = _dev()
+    torch.manual_seed(B + E)
+    query, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=0.3, num_heads=H)
+    pool = pool.to(dev, dtype).train()
+    query = query.detach().to(dev, dtype)
+    x = (torch.randn(B, M, E, device=dev) * torch.linspace(0.5, 3.0, M, device=dev).view(1, M, 1)).to(dtype)
+    out, info = pool(query.expand(B, -1, -1), x, return_info=True)
+    ent = info["entropy"]
+    assert hasattr(ent, "_aecf_entropy_partials")
+    cm = pool.curriculum_masking
+    fast = cm.entropy_loss(ent)
+    plain = cm.entropy_loss(ent.clone())
+    assert fast.dtype == plain.dtype == dtype and fast.shape == plain.shape == ()
+    assert abs(float(fast) - float(plain)) <= 2e-6 * abs(float(plain)) + (4e-3 * abs(float(plain)) if dtype == torch.bfloat16 else 0.0)
+    cm._last_seq_len = M + 1                    # another target than the forward summed against: the stand-alone operator runs
+    other = cm.entropy_loss(ent)
+    assert abs(float(other) - float(cm.entropy_loss(ent.clone()))) <= 1e-6 + 4e-3 * abs(float(other))
+    assert abs(float(other) - float(plain)) > 1e-4
