@@ -545,6 +545,41 @@ def _shared_query_base(query: torch.Tensor) -> Optional[torch.Tensor]:
     return query[:1]
 
 
+def _padded_embed(E: int, H: int, dtype: torch.dtype) -> Optional[Tuple[int, int]]:
+    """(E', head_dim') of the smallest per-head padding the general kernels tile: E' = H * head_dim' a multiple of 64 (bf16) /
+    32 (float32).  None when E already is one."""
+    unit = 64 if dtype == torch.bfloat16 else 32
+    if E % H != 0 or E % unit == 0:
+        return None
+    hd = E // H
+    g = unit // math.gcd(unit, H)
+    hd2 = (hd + g - 1) // g * g
+    return H * hd2, hd2
+
+
+def _pad_heads(w_in, b_in, w_out, b_out, E: int, H: int, pad_to: Tuple[int, int]):
+    """The parameters of an E-wide attention as those of an E'-wide one that computes the same function on zero-padded
+    inputs: every head keeps its head_dim rows of W_q / W_k / W_v (and columns of W_o) at the start of a head_dim'-wide
+    slot, the rest is zero; W_q and b_q carry sqrt(head_dim' / head_dim), because the kernels scale the scores by
+    1 / sqrt(head_dim').  Differentiable torch ops: the gradients reach the original parameters through them."""
+    E2, hd2 = pad_to
+    hd = E // H
+    pad = torch.nn.functional.pad
+    s = math.sqrt(hd2 / hd)
+
+    def rows(w, scale):                                   # [E, E] -> [E', E']
+        return pad(w.reshape(H, hd, E), (0, E2 - E, 0, hd2 - hd)).reshape(E2, E2) * scale
+
+    w_in2 = torch.cat([rows(w_in[:E], s), rows(w_in[E:2 * E], 1.0), rows(w_in[2 * E:], 1.0)])
+    b_in2 = None
+    if b_in is not None:
+        vec = lambda b, scale: pad(b.reshape(H, hd), (0, hd2 - hd)).reshape(E2) * scale
+        b_in2 = torch.cat([vec(b_in[:E], s), vec(b_in[E:2 * E], 1.0), vec(b_in[2 * E:], 1.0)])
+    w_out2 = pad(pad(w_out.reshape(E, H, hd), (0, hd2 - hd)).reshape(E, E2), (0, 0, 0, E2 - E))
+    b_out2 = None if b_out is None else pad(b_out, (0, E2 - E))
+    return w_in2, b_in2, w_out2, b_out2
+
+
 class MultimodalAttentionPool(nn.Module):
     r"""Multimodal attention pooling with optional curriculum masking (ref: aecf/AECFLayer.py:322-552).
 
@@ -682,12 +717,20 @@ class MultimodalAttentionPool(nn.Module):
         general_ok = fast_ok or _lib.load().aecf_mha_check(ctypes.byref(_lib.MhaDesc(
             batch_size, tgt_len, src_len, embed_dim, self.num_heads, _DTYPES[key.dtype], 0.0))) == 0
         float_kpm = key_padding_mask is not None and key_padding_mask.is_floating_point()   # additive in torch
+        pad_to = None
+        if not general_ok:
+            # embedding sizes no kernel tiles (the reference takes any E % H == 0, ref :384-391): every head is padded with
+            # zero rows / columns to the next size the general kernels take -- the same function of the inputs
+            pad_to = _padded_embed(embed_dim, self.num_heads, key.dtype)
+            if pad_to is not None and _lib.load().aecf_mha_check(ctypes.byref(_lib.MhaDesc(
+                    batch_size, tgt_len, src_len, pad_to[0], self.num_heads, _DTYPES[key.dtype], 0.0))) != 0:
+                pad_to = None
         if (q_base is None or not same_kv or attn_mask is not None or dropping or float_kpm
-                or (not fast_ok and general_ok)):
+                or (not fast_ok and general_ok) or pad_to is not None):
             # everything outside the shared-query hot path: the general attention kernels
             return self._forward_general(q_bf, x, value if self.batch_first else value.transpose(0, 1),
                                          key_padding_mask, attn_mask, return_info, batch_size, tgt_len, src_len,
-                                         uniforms, generator)
+                                         uniforms, generator, pad_to)
         kpm = None
         if key_padding_mask is not None:
             if key_padding_mask.shape != (batch_size, src_len):
@@ -774,7 +817,7 @@ class MultimodalAttentionPool(nn.Module):
         return (attn_output, info) if return_info else attn_output
 
     def _forward_general(self, q_bf, k_bf, v_bf, key_padding_mask, attn_mask, return_info, batch_size, tgt_len,
-                         src_len, uniforms=None, generator=None):
+                         src_len, uniforms=None, generator=None, pad_to=None):
         """nn.MultiheadAttention semantics for per-sample queries / tgt_len > 1 / key != value / attn_mask / dropout
         (ref :503-521 -> torch functional.py:5836-5852, 6504-6612), then the curriculum hook exactly as the
         reference applies it to the pooled weights (ref :526-541)."""
@@ -814,8 +857,17 @@ class MultimodalAttentionPool(nn.Module):
         drop_p = float(self.attention.dropout) if (self.attention.dropout > 0.0 and self.training) else 0.0
         drop_u = torch.rand(batch_size * H, tgt_len, src_len, device=dev) if drop_p > 0.0 else None
         a = self.attention
-        y, attn_w = _MhaFunction.apply(q_bf.to(dt), k_bf, v_bf, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight,
-                                       a.out_proj.bias, add_mask, stride, kpm, drop_u, drop_p, H)
+        if pad_to is None:
+            y, attn_w = _MhaFunction.apply(q_bf.to(dt), k_bf, v_bf, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight,
+                                           a.out_proj.bias, add_mask, stride, kpm, drop_u, drop_p, H)
+        else:
+            E = self.embed_dim
+            w_in2, b_in2, w_out2, b_out2 = _pad_heads(a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                                                      E, H, pad_to)
+            wide = lambda t_: torch.nn.functional.pad(t_.to(dt), (0, pad_to[0] - E))
+            y, attn_w = _MhaFunction.apply(wide(q_bf), wide(k_bf), wide(v_bf), w_in2, b_in2, w_out2, b_out2, add_mask, stride,
+                                           kpm, drop_u, drop_p, H)
+            y = y[..., :E]
         attn_output = y if self.batch_first else y.transpose(0, 1)
         attn_weights = attn_w.to(dt)                                           # [B,T,S], always batch-major
 

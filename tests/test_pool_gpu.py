@@ -429,9 +429,6 @@ def test_unsupported_configurations_fail_loudly():
         pool(torch.randn(4, 2, 64, device=dev), x, attn_mask=torch.zeros(3, 3, device=dev))
     with pytest.raises(NotImplementedError):
         pool(torch.randn(4, 1, 64, device=dev).double(), x.double())            # float64 is not built
-    pool40 = aecf_amd.MultimodalAttentionPool(40, num_heads=2).to(dev)          # E not a multiple of 32: no kernel takes it
-    with pytest.raises(RuntimeError, match="not supported"):
-        pool40(torch.randn(1, 1, 40, device=dev).expand(4, -1, -1), torch.randn(4, 3, 40, device=dev))
     cm = aecf_amd.CurriculumMasking().to(dev).train()
     with pytest.raises(NotImplementedError, match="64 keys"):                   # the mask kernels keep a row in registers
         cm(torch.softmax(torch.randn(4, 1, 70, device=dev), -1))
@@ -739,3 +736,45 @@ def test_entropy_loss_from_the_forward_partial_sums(dtype, B, M, E, H):
     other = cm.entropy_loss(ent)
     assert abs(float(other) - float(cm.entropy_loss(ent.clone()))) <= 1e-6 + 4e-3 * abs(float(other))
     assert abs(float(other) - float(plain)) > 1e-4
+
+
+@pytest.mark.parametrize("E,H,dtype,tol", [(40, 2, torch.float32, 1e-5), (100, 4, torch.float32, 1e-5), (24, 3, torch.float32, 1e-5),
+                                           (100, 4, torch.bfloat16, 1.2e-2), (72, 2, torch.bfloat16, 1.2e-2)])
+def test_embed_sizes_no_kernel_tiles_are_served_by_head_padding(E, H, dtype, tol):
+    """The reference takes any embed_dim divisible by num_heads (aecf/AECFLayer.py:384-391).  Sizes that are not multiples of
+    32 (float32) / 64 (bf16) run on the general kernels with every head zero-padded to the next size they tile: outputs,
+    weights, input and parameter gradients against the oracle."""
+    import aecf_amd
+    from oracle import aecf_oracle as O
+    dev = _dev()
+    g = torch.Generator().manual_seed(E + H)
+    B, M = 37, 3
+    rd = lambda *s_: torch.randn(*s_, generator=g)
+    bfr = (lambda t_: t_.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda t_: t_)
+    x, q = bfr(rd(B, M, E)), bfr(rd(1, 1, E) * 0.5)
+    w_in, b_in = bfr(rd(3 * E, E) / E ** 0.5), bfr(rd(3 * E) * 0.05)
+    w_out, b_out = bfr(rd(E, E) / E ** 0.5), bfr(rd(E) * 0.05)
+    dy, dw = bfr(rd(B, 1, E)), rd(B, 1, M)
+    pool = aecf_amd.MultimodalAttentionPool(E, num_heads=H)
+    with torch.no_grad():
+        pool.attention.in_proj_weight.copy_(w_in)
+        pool.attention.in_proj_bias.copy_(b_in)
+        pool.attention.out_proj.weight.copy_(w_out)
+        pool.attention.out_proj.bias.copy_(b_out)
+    pool = pool.to(dev)                                            # float32 master parameters
+    xd = x.to(dev, dtype).requires_grad_(True)
+    qd = q.to(dev).requires_grad_(True)
+    out, info = pool(qd.to(dtype).expand(B, -1, -1), xd, return_info=True)
+    assert out.shape == (B, 1, E)
+    ((out.float() * dy.to(dev)).sum() + (info["attention_weights"].float() * dw.to(dev)).sum()).backward()
+    qe = q.expand(B, -1, -1)
+    f = O.mha_forward(qe, x, x, w_in, b_in, w_out, b_out, H)
+    b = O.mha_backward(qe, x, x, w_in, b_in, w_out, H, f, dy, dw)
+    c = lambda t_: t_.detach().float().cpu()
+    a = pool.attention
+    assert rel_err(c(out), f["y"]) < tol and rel_err(c(info["attention_weights"]), f["wbar"]) < tol
+    assert rel_err(c(xd.grad), b["dkey"] + b["dvalue"]) < tol
+    assert rel_err(c(qd.grad), b["dquery"].sum(0, keepdim=True)) < 2 * tol
+    for got, want in ((a.in_proj_weight.grad, b["dw_in"]), (a.in_proj_bias.grad, b["db_in"]),
+                      (a.out_proj.weight.grad, b["dw_out"]), (a.out_proj.bias.grad, b["db_out"])):
+        assert rel_err(c(got), want) < 2 * tol
