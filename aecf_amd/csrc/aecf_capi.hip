@@ -755,10 +755,10 @@ int aecf_curriculum_mask_forward(int64_t rows, int32_t L, int32_t mode, int32_t 
                                  float entropy_target, float eps, const float* weights, const float* uniforms,
                                  float* masked, float* entropy, float* mask_rate, uint8_t* mask_bits, void* stream) {
     if (rows <= 0 || L <= 0) return AECF_ERR_BAD_DIMS;
-    if (L > 64) return AECF_ERR_UNSUPPORTED;
     if (mode != 1 && mode != 2) return AECF_ERR_BAD_DIMS;
     if (!weights) return AECF_ERR_NULL_POINTER;
     if (mode == 1 && L > 1 && !uniforms) return AECF_ERR_NULL_POINTER;
+    if (mode == 1 && L > 64 && !mask_bits) return AECF_ERR_NULL_POINTER;      // (rows beyond 64 keys keep their bits there)
     MaskCfg c = make_mask_cfg(mode, min_active, base_mask_prob, entropy_target, eps, L);
     launch_mask_fwd(rows, L, c, weights, uniforms, masked, entropy, mask_rate, mask_bits, (hipStream_t)stream);
     return launch_status();
@@ -768,7 +768,6 @@ int aecf_curriculum_mask_backward(int64_t rows, int32_t L, int32_t mode, float e
                                   const uint8_t* mask_bits, const float* d_masked, const float* d_entropy,
                                   float* d_weights, void* stream) {
     if (rows <= 0 || L <= 0) return AECF_ERR_BAD_DIMS;
-    if (L > 64) return AECF_ERR_UNSUPPORTED;
     if (!weights || !d_weights) return AECF_ERR_NULL_POINTER;
     if (mode == 1 && L > 1 && !mask_bits) return AECF_ERR_NULL_POINTER;
     launch_mask_bwd(rows, L, mode, eps, (float)log((double)L), weights, mask_bits, d_masked, d_entropy, d_weights,

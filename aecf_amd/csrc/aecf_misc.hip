@@ -106,6 +106,140 @@ __global__ __launch_bounds__(256) void mask_bwd_kernel(int64_t rows, int L, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// The same two functions for rows of ANY length (the reference's module is length-agnostic, ref :130-283): one wave per row,
+// key i belongs to lane i % 64 throughout, every sum is the lanes' partial sums (ascending i) folded by the wave butterfly.
+// The keep bits live in the caller's mask_bits bytes (required in train mode); a lane only ever reads back bytes it wrote.
+__global__ __launch_bounds__(256) void mask_fwd_long_kernel(int64_t rows, int L, MaskCfg c, const float* __restrict__ w,
+                                                            const float* __restrict__ u, float* __restrict__ masked,
+                                                            float* __restrict__ entropy, float* __restrict__ mask_rate,
+                                                            uint8_t* __restrict__ bits) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave_id();
+    if (row >= rows) return;                                      // (whole waves)
+    const int lane = lane_id();
+    const float* wr = w + row * L;
+    if (c.mode == 2) {                                            // eval (ref :150-156)
+        float h = 0.f;
+        for (int i = lane; i < L; i += 64) {
+            h -= xlogx(wr[i]);
+            if (masked) masked[row * L + i] = wr[i];
+            if (bits) bits[row * L + i] = 1;
+        }
+        h = reduce_wave(h);
+        float e = fminf(fmaxf(h, 0.f), c.log_L);
+        if (h != h) e = h;
+        if (lane == 0) {
+            if (entropy) entropy[row] = e;
+            if (mask_rate) mask_rate[row] = 0.f;
+        }
+        return;
+    }
+    // ref :170-184
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) { const float v = wr[i]; s += isfinite(v) ? v : 0.f; }
+    s = reduce_wave(s);
+    const bool needs_norm = s < c.eps;
+    auto wn = [&](int i) -> float { const float v = wr[i]; return needs_norm ? c.inv_L : ((isfinite(v) ? v : 0.f) / s); };
+    // ref :190-201
+    float h = 0.f;
+    for (int i = lane; i < L; i += 64) h -= xlogx(wn(i));
+    h = fminf(fmaxf(reduce_wave(h), 0.f), c.log_L);
+    const float ne = fminf(fmaxf(h / c.log_L, 0.f), 1.f);
+    const float keep = fminf(fmaxf(1.0f - c.base_mask_prob * ne, 0.f), 1.f);
+    // ref :204
+    uint8_t* br = bits + row * L;
+    float act = 0.f;
+    for (int i = lane; i < L; i += 64) {
+        const uint8_t b = u[row * L + i] < keep ? 1 : 0;
+        br[i] = b;
+        act += (float)b;
+    }
+    int active = (int)(reduce_wave(act) + 0.5f);                  // (exact: integers below 2^24)
+    // ref :207-260: rows with too few survivors keep exactly their top-k weights (lowest index on ties)
+    const int k = c.min_active < L ? c.min_active : L;
+    if (active < k) {
+        for (int i = lane; i < L; i += 64) br[i] = 0;
+        for (int t = 0; t < k; ++t) {
+            float bv = -INFINITY;
+            int best = 0x7fffffff;
+            for (int i = lane; i < L; i += 64) {
+                const float v = wn(i);
+                if (!br[i] && (best == 0x7fffffff || v > bv)) { bv = v; best = i; }
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float ov = __shfl_xor(bv, off, 64);
+                const int oi = __shfl_xor(best, off, 64);
+                if (oi != 0x7fffffff && (best == 0x7fffffff || ov > bv || (ov == bv && oi < best))) { bv = ov; best = oi; }
+            }
+            if ((best & 63) == lane) br[best] = 1;
+        }
+        active = k;
+    }
+    // ref :263-272
+    float ms = 0.f;
+    for (int i = lane; i < L; i += 64) ms += br[i] ? wn(i) : 0.f;
+    ms = reduce_wave(ms);
+    const bool valid = ms > c.eps;
+    if (masked)
+        for (int i = lane; i < L; i += 64) {
+            const float v = wn(i);
+            masked[row * L + i] = valid ? ((br[i] ? v : 0.f) / ms) : v;
+        }
+    if (lane == 0) {
+        if (entropy) entropy[row] = h;
+        if (mask_rate) mask_rate[row] = 1.0f - (float)active / (float)L;     // ref :275
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_bwd_long_kernel(int64_t rows, int L, int mode, float eps, float log_L,
+                                                            const float* __restrict__ w, const uint8_t* __restrict__ bits,
+                                                            const float* __restrict__ d_masked,
+                                                            const float* __restrict__ d_entropy, float* __restrict__ d_w) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave_id();
+    if (row >= rows) return;
+    const int lane = lane_id();
+    const float* wr = w + row * L;
+    const float* gr = d_masked ? d_masked + row * L : nullptr;
+    float* out = d_w + row * L;
+    if (mode == 2) {
+        float h = 0.f;
+        for (int i = lane; i < L; i += 64) h -= xlogx(wr[i]);
+        h = reduce_wave(h);
+        const bool live = (h >= 0.f) && (h <= log_L);
+        const float de = d_entropy ? d_entropy[row] : 0.f;
+        for (int i = lane; i < L; i += 64)
+            out[i] = (gr ? gr[i] : 0.f) + ((live && d_entropy) ? -(logf(wr[i]) + 1.0f) * de : 0.f);
+        return;
+    }
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) { const float v = wr[i]; s += isfinite(v) ? v : 0.f; }
+    s = reduce_wave(s);
+    if (s < eps) {                                                // uniform fallback: no dependence on the weights
+        for (int i = lane; i < L; i += 64) out[i] = 0.f;
+        return;
+    }
+    const uint8_t* br = bits + row * L;
+    auto wn = [&](int i) -> float { const float v = wr[i]; return (isfinite(v) ? v : 0.f) / s; };
+    float ms = 0.f;
+    for (int i = lane; i < L; i += 64) ms += br[i] ? wn(i) : 0.f;
+    ms = reduce_wave(ms);
+    const bool valid = ms > eps;
+    float dot = 0.f;
+    if (valid) {
+        for (int i = lane; i < L; i += 64) dot += br[i] ? (gr ? gr[i] : 0.f) * (wn(i) / ms) : 0.f;
+        dot = reduce_wave(dot);
+    }
+    auto dwn = [&](int i) -> float {
+        const float g = gr ? gr[i] : 0.f;
+        return valid ? (br[i] ? (g - dot) / ms : 0.f) : g;
+    };
+    float dot2 = 0.f;
+    for (int i = lane; i < L; i += 64) dot2 += dwn(i) * wn(i);
+    dot2 = reduce_wave(dot2);
+    for (int i = lane; i < L; i += 64) out[i] = isfinite(wr[i]) ? (dwn(i) - dot2) / s : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
 // entropy_loss (ref aecf/AECFLayer.py:285-314): mean((nan_to_num(H) - target)^2), two-stage reduce
 __device__ __forceinline__ float nan_to_num_ref(float e) {   // nan=0, +inf=1, -inf=0 (ref :296)
     if (e != e) return 0.f;
@@ -238,7 +372,8 @@ void launch_mask_fwd(int64_t rows, int L, const MaskCfg& cfg, const float* w, co
     else if (L <= 8) mask_fwd_kernel<8><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
     else if (L <= 16) mask_fwd_kernel<16><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
     else if (L <= 32) mask_fwd_kernel<32><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
-    else mask_fwd_kernel<64><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);     // 64-bit keep word
+    else if (L <= 64) mask_fwd_kernel<64><<<grid, block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);     // 64-bit keep word
+    else mask_fwd_long_kernel<<<dim3((unsigned)((rows + 3) / 4)), block, 0, s>>>(rows, L, cfg, w, u, masked, entropy, mask_rate, bits);
 }
 
 void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, const float* w, const uint8_t* bits,
@@ -248,7 +383,8 @@ void launch_mask_bwd(int64_t rows, int L, int mode, float eps, float log_L, cons
     else if (L <= 8) mask_bwd_kernel<8><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
     else if (L <= 16) mask_bwd_kernel<16><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
     else if (L <= 32) mask_bwd_kernel<32><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
-    else mask_bwd_kernel<64><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
+    else if (L <= 64) mask_bwd_kernel<64><<<grid, block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
+    else mask_bwd_long_kernel<<<dim3((unsigned)((rows + 3) / 4)), block, 0, s>>>(rows, L, mode, eps, log_L, w, bits, d_masked, d_entropy, d_w);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -483,9 +483,6 @@ class CurriculumMasking(nn.Module):
         _require_device(weights, "weights")
         dt = weights.dtype
         seq_len = weights.size(-1)
-        if seq_len > 64:
-            raise NotImplementedError(f"aecf_amd: CurriculumMasking over {seq_len} keys is not built (the mask kernels keep "
-                                      "a row in registers: up to 64 keys; the reference's callers use 2-4 modalities)")
         if not self.training:                                                 # ref :150-156
             _, entropy, mask_rate = _MaskFunction.apply(weights, None, 2, self.min_active,
                                                         float(self.base_mask_prob), float(self.entropy_target), 1e-8)

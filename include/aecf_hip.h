@@ -198,8 +198,8 @@ int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void
 int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream);
 
 /* Stand-alone CurriculumMasking.forward on rows of length L (ref aecf/AECFLayer.py:130-283).
- * weights [rows,L] float32.  mode 1 = train (uniforms required), 2 = eval.
- * Any output pointer may be NULL. */
+ * weights [rows,L] float32, any L.  mode 1 = train (uniforms required), 2 = eval.
+ * Any output pointer may be NULL -- except mask_bits in train mode when L > 64 (rows that long keep their bits there). */
 int aecf_curriculum_mask_forward(int64_t rows, int32_t L, int32_t mode, int32_t min_active,
                                  float base_mask_prob, float entropy_target, float eps,
                                  const float* weights, const float* uniforms,

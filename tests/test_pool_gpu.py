@@ -429,15 +429,13 @@ def test_unsupported_configurations_fail_loudly():
         pool(torch.randn(4, 2, 64, device=dev), x, attn_mask=torch.zeros(3, 3, device=dev))
     with pytest.raises(NotImplementedError):
         pool(torch.randn(4, 1, 64, device=dev).double(), x.double())            # float64 is not built
-    cm = aecf_amd.CurriculumMasking().to(dev).train()
-    with pytest.raises(NotImplementedError, match="64 keys"):                   # the mask kernels keep a row in registers
-        cm(torch.softmax(torch.randn(4, 1, 70, device=dev), -1))
 
 
-@pytest.mark.parametrize("L", [33, 40, 64])
-def test_curriculum_masking_over_33_to_64_keys(L):
-    """The stand-alone masking takes up to 64 keys (a 64-bit keep word per row; the reference is length-agnostic,
-    aecf/AECFLayer.py:130-283): mask pattern bit-exact, weights / entropy / mask rate and the gradient against the oracle."""
+@pytest.mark.parametrize("L", [33, 40, 64, 65, 70, 200, 1000])
+def test_curriculum_masking_over_more_than_32_keys(L):
+    """The stand-alone masking takes rows of any length, as the reference does (aecf/AECFLayer.py:130-283): a 64-bit keep word
+    per row up to 64 keys, one wave per row beyond.  Mask pattern bit-exact, weights / entropy / mask rate and the gradient
+    against the oracle; eval mode (identity + entropy, with its gradient) on the long rows too."""
     import aecf_amd
     from oracle import aecf_oracle as O
     dev = _dev()
@@ -461,6 +459,14 @@ def test_curriculum_masking_over_33_to_64_keys(L):
         mm = wn * keep
         (mm / mm.sum(-1, keepdim=True) * dm).sum().backward()
         assert rel_err(wd.grad.cpu(), wr.grad) < 1e-5
+    cm = aecf_amd.CurriculumMasking().to(dev).eval()
+    wd = w.to(dev).requires_grad_(True)
+    same, info = cm(wd)
+    want = O.curriculum_mask_eval(w)
+    assert torch.equal(same.detach().cpu(), w) and rel_err(info["entropy"].detach().cpu(), want["entropy"]) < 1e-6
+    de = torch.randn(300, 1, generator=g)
+    (info["entropy"] * de.to(dev)).sum().backward()
+    assert rel_err(wd.grad.cpu(), O.entropy_rows_backward(w, de)) < 1e-5
 
 
 def test_shapes_outside_the_shared_query_kernels_use_the_general_path():
