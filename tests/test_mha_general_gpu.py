@@ -125,6 +125,30 @@ def test_general_path_with_curriculum_masking_info_contract():
     assert cm._last_seq_len == M
 
 
+def test_general_path_masks_rows_of_100_keys():
+    """A pooled sequence of 100 keys with curriculum masking (the reference's module is length-agnostic, ref :130-283; the
+    mask kernels take any row length): weights, masked weights and pattern against the oracle on the kernel's own weights."""
+    import aecf_amd
+    from oracle import aecf_oracle as O
+    B, S, E, H = 48, 100, 64, 4
+    g = torch.Generator().manual_seed(100)
+    q, pool = aecf_amd.create_fusion_pool(E, S, num_heads=H)
+    pool.curriculum_masking = aecf_amd.CurriculumMasking(base_mask_prob=0.5, min_active=2)
+    pool = pool.to(DEV).train()
+    x = torch.randn(B, S, E, generator=g)
+    U = torch.rand(B, 1, S, generator=g)
+    a = pool.attention
+    cpu = lambda t_: t_.detach().float().cpu()
+    y, info = pool(q.to(DEV).expand(B, -1, -1), x.to(DEV), return_info=True, uniforms=U)
+    f, m = O.pool_forward_train(cpu(q).expand(B, -1, -1), x, cpu(a.in_proj_weight), cpu(a.in_proj_bias), cpu(a.out_proj.weight),
+                                cpu(a.out_proj.bias), H, U, 0.5, min_active=2)
+    assert rel_err(cpu(y), f["y"]) < 1e-5 and rel_err(cpu(info["attention_weights"]), f["wbar"]) < 1e-5
+    mine = O.curriculum_mask_train(cpu(info["attention_weights"]), U, 0.5, min_active=2)
+    assert torch.equal(cpu(info["masked_attention_weights"]) != 0, mine["masked"] != 0)
+    assert rel_err(cpu(info["masked_attention_weights"]), mine["masked"]) < 1e-5
+    assert rel_err(cpu(info["entropy"]), m["entropy"]) < 1e-5
+
+
 def test_functional_slow_path_matches_reference_g7():
     """SURVEY 8a row A8, ref aecf/AECFLayer.py:643-652: anything but the projection-free fast path builds a FRESH randomly
     initialised module per call (CPU generator state at call time) and runs it.  Fixtures g7 slow_seed71_h4 (E = 32, 4
