@@ -435,8 +435,13 @@ def main():
         dp.broadcast_parameters(params)      # replicas start identical whatever the ranks' construction RNG did
         # (no dp.probe_avg_support here: the step uses divide + ReduceOp.SUM, which every backend takes; ReduceOp.AVG would
         #  save one 1 M-element divide per step and its start-up probe is one more thing that has never run on real RCCL)
-    # curriculum-mask uniforms: every rank draws the SAME global tensor (shared seed, own generator) and uses its rows
-    ugen = torch.Generator(device=device).manual_seed(1234) if world > 1 else None
+    # curriculum-mask uniforms (public `uniforms=` argument).  Weak scaling: the global draw is DEFINED slot by slot -- rows
+    # [r Bc, (r + 1) Bc) come from the generator seeded 1234 + r -- so a rank draws exactly its own Bc rows per step (per-rank work
+    # does not grow with N) and any number of ranks, or one rank walking the slots, sees the same global tensor.  Strong scaling
+    # (shard sizes change with N): every rank draws the same global tensor from the shared seed and uses its rows.
+    ugen = None
+    if world > 1:
+        ugen = torch.Generator(device=device).manual_seed(1234 + (rank if args.scaling != "strong" else 0))
     overlap = dp.GradOverlap(params=params) if (world > 1 and args.overlap and not args.no_overlap) else None
 
     # --contrastive (configs[2]): the paired view.  zb_local = this rank's rows of the other view (resident, as the output of a
@@ -480,7 +485,10 @@ def main():
     def one_step():
         u = None
         if ugen is not None:
-            u = torch.rand(B_global, 1, M, device=device, dtype=torch.float32, generator=ugen)[lo:lo + B]
+            if args.scaling == "strong":
+                u = torch.rand(B_global, 1, M, device=device, dtype=torch.float32, generator=ugen)[lo:lo + B]
+            else:
+                u = torch.rand(B, 1, M, device=device, dtype=torch.float32, generator=ugen)
         if nce is not None:
             return contrastive_step(u)
         return step(pool, query, x, dy, params, world > 1, u, overlap)
