@@ -312,16 +312,21 @@ class _AllGatherRows(torch.autograd.Function):
     shard summed over ranks (reduce-scatter; all-reduce + slice where the backend has no reduce_scatter)."""
 
     @staticmethod
-    def forward(ctx, z, group):
+    def forward(ctx, z, group, sizes=None):
         rank, world = world_info(group)
         ctx.group, ctx.rank, ctx.world = group, rank, world
         if world == 1:
             ctx.sizes = [z.shape[0]]
             return z.clone()
-        n = torch.tensor([z.shape[0]], device=z.device, dtype=torch.int64)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n, group=group)
-        ctx.sizes = [int(s.item()) for s in sizes]
+        if sizes is not None:                               # the caller knows every rank's row count: no exchange, no host sync
+            ctx.sizes = [int(v) for v in sizes]
+            if len(ctx.sizes) != world or ctx.sizes[rank] != z.shape[0]:
+                raise ValueError(f"all_gather_rows: sizes {ctx.sizes} do not describe {world} ranks with {z.shape[0]} rows here")
+        else:
+            n = torch.tensor([z.shape[0]], device=z.device, dtype=torch.int64)
+            got = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(got, n, group=group)
+            ctx.sizes = [int(v.item()) for v in got]
         zc = z.contiguous()
         if len(set(ctx.sizes)) == 1:
             out = torch.empty(world * zc.shape[0], *zc.shape[1:], dtype=z.dtype, device=z.device)
@@ -334,7 +339,7 @@ class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz_all):
         if ctx.world == 1:
-            return dz_all, None
+            return dz_all, None, None
         lo = sum(ctx.sizes[:ctx.rank])
         hi = lo + ctx.sizes[ctx.rank]
         dz_all = dz_all.contiguous()
@@ -342,14 +347,15 @@ class _AllGatherRows(torch.autograd.Function):
         if even and dist.get_backend(ctx.group) == "nccl":
             out = torch.empty(ctx.sizes[ctx.rank], *dz_all.shape[1:], dtype=dz_all.dtype, device=dz_all.device)
             dist.reduce_scatter_tensor(out, dz_all, op=dist.ReduceOp.SUM, group=ctx.group)
-            return out, None
+            return out, None, None
         dist.all_reduce(dz_all, op=dist.ReduceOp.SUM, group=ctx.group)
-        return dz_all[lo:hi].clone(), None
+        return dz_all[lo:hi].clone(), None, None
 
 
-def all_gather_rows(z: torch.Tensor, group=None) -> torch.Tensor:
-    """Autograd-aware all-gather of fused embeddings (cross-batch contrastive negatives)."""
-    return _AllGatherRows.apply(z, group)
+def all_gather_rows(z: torch.Tensor, group=None, sizes=None) -> torch.Tensor:
+    """Autograd-aware all-gather of fused embeddings (cross-batch contrastive negatives).  ``sizes`` (every rank's row count,
+    rank order) skips the small exchange + host read that otherwise finds them out on every call."""
+    return _AllGatherRows.apply(z, group, sizes)
 
 
 def all_reduce_mean_scalar(v: torch.Tensor, weight: float = 1.0, group=None) -> torch.Tensor:

@@ -470,7 +470,7 @@ def main():
             nb_all = nce["keys"]
             nb_all[nce["offset"]:nce["offset"] + B] = nb            # the gather's local slot
         else:
-            nb_all = dp.all_gather_rows(nb)
+            nb_all = dp.all_gather_rows(nb, sizes=[B] * world if args.scaling != "strong" else None)
         loss = losses.gathered_contrastive_entropy_loss(out.squeeze(1), nb_all, nce["offset"], pool.curriculum_masking,
                                                         info["entropy"], temperature=NCE_TEMPERATURE)
         x.grad = None

@@ -52,6 +52,12 @@ def _worker(rank, world, port, q):
         z_all = dp.all_gather_rows(z)
         w = torch.arange(B * 4, dtype=torch.float32).reshape(B, 4)
         (z_all * w).sum().backward()
+        # ... and with the row counts given by the caller (no size exchange): same rows, same gradient
+        z2 = z.detach().clone().requires_grad_(True)
+        sizes = [dp.shard_bounds(B, r, world)[1] - dp.shard_bounds(B, r, world)[0] for r in range(world)]
+        z_all2 = dp.all_gather_rows(z2, sizes=sizes)
+        (z_all2 * w).sum().backward()
+        assert torch.equal(z_all2, z_all) and torch.equal(z2.grad, z.grad)
         u = dp.global_uniforms(B, 1, 3, seed=123, device="cpu")
         mean_stat = dp.all_reduce_mean_scalar(x[lo:hi].mean(), weight=hi - lo)
         # replicas built under different RNG states are made identical by broadcast_parameters
