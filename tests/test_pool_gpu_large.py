@@ -154,3 +154,53 @@ def test_full_size_fp32_c2_chunk():
     assert rel_err(c(got["dq"]), b["dquery"].sum(0, keepdim=True)) < 1e-5
     m = O.curriculum_mask_train(c(got["w"]), U[:n], 0.15)
     assert torch.equal(c(got["mw"]) != 0, m["masked"] != 0)          # oracle masking of the kernel's own weights
+
+
+def test_batch_whose_input_exceeds_4_gib():
+    """1.5 M samples at the headline shape: x is 4.6 GB, so byte offsets into it, into dx and into the saved tensors pass
+    2^32 (and the element count 2^31).  Size-independent properties only: rows beyond the boundary, and a slice that straddles
+    it, reproduce bit for bit when run on their own; parameter gradients add up over the two halves; a second run is
+    bit-identical."""
+    import aecf_amd
+    dev = torch.device("cuda:0")
+    B, M, E, H = 1_500_000, 3, 512, 8
+    dt = torch.bfloat16
+    torch.manual_seed(11)
+    query, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=0.15, num_heads=H)
+    pool = pool.to(dev).train()                               # float32 master parameters, bf16 activations
+    query = query.detach().to(dev).requires_grad_(True)
+    g = torch.Generator(device=dev).manual_seed(12)
+    x = torch.randn(B, M, E, device=dev, dtype=dt, generator=g)
+    x[:, 1] *= 1.75
+    dy = torch.randn(B, 1, E, device=dev, dtype=dt, generator=g)
+    U = torch.rand(B, 1, M, device=dev, generator=g)
+    assert x.numel() * x.element_size() > 2 ** 32 and x.numel() > 2 ** 31
+
+    def run(sl):
+        xs = x[sl].detach().requires_grad_(True)
+        for p in pool.parameters():
+            p.grad = None
+        query.grad = None
+        n = xs.shape[0]
+        out, info = pool(query.expand(n, -1, -1), xs, return_info=True, uniforms=U[sl])
+        torch.autograd.backward([out], [dy[sl]])
+        torch.cuda.synchronize()
+        a = pool.attention
+        return dict(y=out.detach(), w=info["attention_weights"].detach(), mw=info["masked_attention_weights"].detach(),
+                    dx=xs.grad, dq=query.grad.clone(), dw_in=a.in_proj_weight.grad.clone(), db_in=a.in_proj_bias.grad.clone(),
+                    dw_out=a.out_proj.weight.grad.clone(), db_out=a.out_proj.bias.grad.clone())
+
+    full = run(slice(0, B))
+    assert bool(torch.isfinite(full["dx"][-1].float()).all()) and bool(torch.isfinite(full["dw_in"]).all())
+    edge = 2 ** 32 // (M * E * 2)                             # the row whose bytes straddle offset 2^32
+    for sl in (slice(B - 4096, B), slice(edge - 2048, edge + 2048)):
+        part = run(sl)
+        for k in ("y", "w", "mw", "dx"):
+            assert torch.equal(part[k], full[k][sl]), (k, sl)
+    again = run(slice(0, B))
+    for k in ("y", "dx", "dw_in", "db_in", "dw_out", "db_out", "dq"):
+        assert torch.equal(again[k], full[k]), k
+    h = B // 2
+    lo, hi = run(slice(0, h)), run(slice(h, B))
+    for k in ("dw_in", "dw_out", "db_in", "db_out", "dq"):
+        assert rel_err(lo[k] + hi[k], full[k]) < 5e-5, k
