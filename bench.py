@@ -531,7 +531,10 @@ def main():
         marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    per_step_raw = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if os.environ.get("AECF_BENCH_DUMP_STEPS"):
+        print("step_ms", [round(v, 4) for v in per_step_raw], file=sys.stderr)
+    per_step = sorted(per_step_raw)
     median_ms = per_step[len(per_step) // 2]
     if world > 1:
         import torch.distributed as dist
