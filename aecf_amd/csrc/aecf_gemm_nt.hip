@@ -24,7 +24,6 @@ template <typename T, int M_, bool POOLED>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
-    typedef typename X::frag frag;
     constexpr int NA = POOLED ? M_ : 1;          // A-side LDS tiles (one per modality when pooling)
     constexpr int TILE = 128 * TILE_ROW_BYTES;   // 16 KB
     constexpr int BK = TileK<T>::value;

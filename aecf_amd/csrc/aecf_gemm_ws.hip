@@ -603,7 +603,6 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     constexpr int PSTR = HBL * M_ * 16;                           // floats per partial block (one per wave)
     constexpr int DSROW = 72;                                     // ds operand row (64 K slots + 8): rows start 9 x 16 B apart
     constexpr int XT = XROWS * ROWX, DT = 16 * ROWD;
-    constexpr int HM = HBL * M_;
     constexpr int NPART = 8;                                      // partial dots per (sample, head, m): one per wave (its four
                                                                   // lane groups are added in registers: v_permlane16/32_swap)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -966,8 +965,11 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
             const int bc = b < ov ? b : ov - 1;
             const unsigned int voff = (unsigned)(bc * M_ + m) * row_pitch + (unsigned)(((lane & 7) ^ (b & 7)) << 4);
             const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(dst0 + 1024 * i);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 is named as a clobber on purpose
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst)
                          : "memory", "m0");
+#pragma clang diagnostic pop
         }
     };
     issue(o_beg, 0);
