@@ -1,15 +1,13 @@
 // extern "C" entry points of libaecf_hip.so (declared in include/aecf_hip.h).
 // Host-side orchestration only: validates the description, carves the caller's workspace and
-// enqueues the kernels on the caller's stream (the pool forward / backward as one executable graph per call, see
-// run_as_graph).  No device allocation, no synchronisation, no exceptions.
+// enqueues the kernels on the caller's stream -- plain launches, so a caller that captures its stream (a whole training step
+// as one HIP graph) gets them as nodes of ITS graph.  No device allocation, no synchronisation, no exceptions, no state.
 #include <math.h>
 #include <stdio.h>
 #include <string>
 #include <stdint.h>
 #include <stdlib.h>
 
-#include <mutex>
-#include <vector>
 
 #include "../../include/aecf_hip.h"
 #include "aecf_kernels.h"
@@ -19,7 +17,7 @@ using namespace aecf;
 namespace {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-int env_dx_reserve();          // tokens of the one debug knob AECF_DEBUG, read once per process (defined with the graph cache;
+int env_dx_reserve();          // tokens of the one debug knob AECF_DEBUG, read once per process (defined below;
 bool env_no_gate_fusion();     //  env_no_ws / env_no_wide_tn / env_no_slab are declared in aecf_kernels.h: other files ask too)
 bool env_fused_fwd();
 inline int esize(int dtype) { return dtype == AECF_BF16 ? 2 : 4; }
@@ -240,7 +238,7 @@ size_t aecf_pool_prep_bytes(const aecf_pool_desc* d) {
 
 namespace {
 
-// validation + every launch of the forward on stream s (the caller's stream, or the capture stream of run_as_graph)
+// validation + every launch of the forward on stream s (the caller's stream)
 int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStream_t s) {
     int st = aecf_pool_check(d);
     if (st != AECF_OK) return st;
@@ -525,52 +523,7 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     return launch_status();
 }
 
-// ---- executable-graph launch of one call ------------------------------------------------------------------------
-// Small dependent kernels launched one by one on a stream pay ~4 us per boundary on this part and ~3 us of host time
-// each; the same chain replayed as a HIP graph pays ~1.6 us per node (tools/micro/launch_floor.hip, graph_update.hip).
-// A call shape that KEEPS COMING BACK is therefore captured on a library-owned stream of its device (the caller's may be
-// the legacy stream, which cannot capture), the cached executable graph of that shape is updated with the captured one
-// (same topology, new pointers: cheaper than the plain launches it replaces) and launched on the caller's stream.
-// Arguments are snapshotted at launch, so updating while earlier launches are queued is safe
-// (tools/micro/graph_update_check.hip, tests/test_pool_gpu.py::test_graph_replay_back_to_back).
-// Bounded state, all of it behind one mutex:
-//   * a shape is instantiated only after GRAPH_MIN_SIGHTINGS calls with the same key (a caller whose batch changes every
-//     step -- xray.AECFModel feeds the count of both-present rows -- never pays a capture + instantiate);
-//   * at most GRAPH_CACHE_SLOTS executables live at once, least-recently-used evicted with hipGraphExecDestroy;
-//   * the key carries the device ordinal and every device has its own capture stream.
-// Anything unexpected falls back to the plain launches.
-struct GraphKey {
-    int kind;                 // 0 forward, 1 backward
-    int device;
-    int64_t batch;
-    int M, E, H, dtype, mask_mode, topo;
-    bool operator==(const GraphKey& o) const {
-        return kind == o.kind && device == o.device && batch == o.batch && M == o.M && E == o.E && H == o.H &&
-               dtype == o.dtype && mask_mode == o.mask_mode && topo == o.topo;
-    }
-};
-struct GraphSlot {
-    GraphKey key;
-    hipGraphExec_t exec;
-    uint64_t last_use;
-};
-struct GraphSighting {
-    GraphKey key;
-    int count;
-    uint64_t last_use;
-};
-constexpr int GRAPH_CACHE_SLOTS = 8;
-constexpr int GRAPH_SIGHTING_SLOTS = 32;
-constexpr int GRAPH_MIN_SIGHTINGS = 3;
-constexpr int MAX_DEVICES = 16;
-std::mutex g_graph_mu;
-std::vector<GraphSlot> g_graph_cache;
-std::vector<GraphSighting> g_graph_seen;
-hipStream_t g_capture_stream[MAX_DEVICES] = {};
-uint64_t g_graph_clock = 0;
-
 // ONE debug knob, read once per process (tests and A/B timing; never on the call path): AECF_DEBUG = comma-separated tokens
-//   graph=0 | graph=1   force HIP-graph replay of a call off / on (default: by call size, graphs_enabled below)
 //   no_ws               tiled round-1 kernels instead of the weight-stationary ones
 //   no_gate_fusion      scores / softmax as their own kernel instead of inside the value projection
 //   no_wide_tn          128-row tiles instead of the 1024-thread 256-row form of the pooled batch reduction
@@ -578,7 +531,6 @@ uint64_t g_graph_clock = 0;
 //   fused_fwd           the one-kernel forward north_star names (aecf_row_fwd.hip; measured slower: profiles/r03_c2_fusedfwd_*)
 //   dx_reserve=N        CUs the dx kernel leaves free when it runs beside a collective (default 16, 0..128)
 struct EnvSwitches {
-    int graph = -1;
     bool no_ws = false, no_gate_fusion = false, no_wide_tn = false, no_slab = false, fused_fwd = false;
     int dx_reserve = 16;
 };
@@ -594,9 +546,7 @@ const EnvSwitches& env_switches() {
             if (end == std::string::npos) end = all.size();
             const std::string tok = all.substr(pos, end - pos);
             pos = end + 1;
-            if (tok == "graph=0") v.graph = 0;
-            else if (tok == "graph=1") v.graph = 1;
-            else if (tok == "no_ws") v.no_ws = true;
+            if (tok == "no_ws") v.no_ws = true;
             else if (tok == "no_gate_fusion") v.no_gate_fusion = true;
             else if (tok == "no_wide_tn") v.no_wide_tn = true;
             else if (tok == "no_slab") v.no_slab = true;
@@ -622,133 +572,15 @@ bool env_no_ws() { return env_switches().no_ws; }
 bool env_no_wide_tn() { return env_switches().no_wide_tn; }
 bool env_no_slab() { return env_switches().no_slab; }
 }  // namespace aecf
-namespace {
-
-// Measured (C2, same box, 3 x A/B): the graph form halves the HOST cost of a step (0.39 -> 0.20 ms) but the GPU runs the
-// large kernels ~2 % slower under it (0.632 vs 0.619 ms), so it is used where the host is the bound: calls whose
-// activations are small (B*M*E up to 2^25 elements; the configs[2] shard at 8192 rows per GPU goes 0.37 -> 0.27 ms).
-// AECF_DEBUG=graph=0 / graph=1 forces it off / on (A/B timing and tests; forced on also skips the sightings threshold).
-bool graphs_enabled(const aecf_pool_desc* d) {
-    const int forced = env_switches().graph;
-    if (forced >= 0) return forced != 0;
-    return (int64_t)d->batch * d->modalities * d->embed_dim <= ((int64_t)1 << 25);
-}
-
-// runs body(capture stream) as ONE executable graph on `user`; false = nothing was enqueued (the caller launches plainly)
-template <class F>
-bool run_as_graph(GraphKey key, hipStream_t user, F&& body, int* status) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(user, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return false;                                   // the caller is capturing: our launches join ITS graph
-    }
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return false; }
-    key.device = dev;
-    std::lock_guard<std::mutex> lock(g_graph_mu);       // capture + update + launch of one call are one critical section
-    const uint64_t now = ++g_graph_clock;
-    GraphSlot* slot = nullptr;
-    for (auto& sl : g_graph_cache)
-        if (sl.key == key) { slot = &sl; break; }
-    if (!slot && env_switches().graph != 1) {           // not cached yet: count the sighting, stay on plain launches
-        GraphSighting* seen = nullptr;
-        for (auto& sg : g_graph_seen)
-            if (sg.key == key) { seen = &sg; break; }
-        if (!seen) {
-            if ((int)g_graph_seen.size() < GRAPH_SIGHTING_SLOTS) {
-                g_graph_seen.push_back(GraphSighting{key, 0, now});
-                seen = &g_graph_seen.back();
-            } else {                                    // recycle the least recently seen entry
-                seen = &g_graph_seen[0];
-                for (auto& sg : g_graph_seen)
-                    if (sg.last_use < seen->last_use) seen = &sg;
-                *seen = GraphSighting{key, 0, now};
-            }
-        }
-        seen->last_use = now;
-        if (++seen->count < GRAPH_MIN_SIGHTINGS) return false;
-    }
-    hipStream_t& cap = g_capture_stream[dev];
-    if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
-        cap = nullptr;
-        return false;
-    }
-    if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    const int rc = body(cap);
-    hipGraph_t g = nullptr;
-    if (hipStreamEndCapture(cap, &g) != hipSuccess || g == nullptr || rc != AECF_OK) {
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        if (rc != AECF_OK) { *status = rc; return true; }      // a validation error: report it, nothing to launch
-        return false;
-    }
-    bool ok = false;
-    if (slot) {
-        hipGraphExecUpdateResult res;
-        hipGraphNode_t bad = nullptr;
-        if (hipGraphExecUpdate(slot->exec, g, &bad, &res) != hipSuccess) {        // topology changed: rebuild
-            (void)hipGetLastError();
-            (void)hipGraphExecDestroy(slot->exec);
-            slot->exec = nullptr;
-            if (hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0) != hipSuccess) slot->exec = nullptr;
-        }
-    } else {
-        hipGraphExec_t ex = nullptr;
-        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
-            if ((int)g_graph_cache.size() >= GRAPH_CACHE_SLOTS) {                 // evict the least recently used
-                size_t lru = 0;
-                for (size_t i = 1; i < g_graph_cache.size(); ++i)
-                    if (g_graph_cache[i].last_use < g_graph_cache[lru].last_use) lru = i;
-                (void)hipGraphExecDestroy(g_graph_cache[lru].exec);
-                g_graph_cache.erase(g_graph_cache.begin() + lru);
-            }
-            g_graph_cache.push_back(GraphSlot{key, ex, now});
-            slot = &g_graph_cache.back();
-        }
-    }
-    if (slot && slot->exec) {
-        slot->last_use = now;
-        ok = hipGraphLaunch(slot->exec, user) == hipSuccess;
-    }
-    if (slot && !slot->exec) {                      // could not be built: forget the slot
-        for (size_t i = 0; i < g_graph_cache.size(); ++i)
-            if (&g_graph_cache[i] == slot) { g_graph_cache.erase(g_graph_cache.begin() + i); break; }
-    }
-    (void)hipGraphDestroy(g);
-    if (!ok) { (void)hipGetLastError(); return false; }
-    *status = AECF_OK;
-    return true;
-}
-
-}  // namespace
 
 extern "C" {
 
 int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream) {
-    hipStream_t user = (hipStream_t)stream;
-    if (d && a && !a->stage_events && !(a->flags & AECF_PRECISE) && graphs_enabled(d)) {   // (stage events / precise: plain launches)
-        const GraphKey key{0, 0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
-                           (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->key_padding_mask ? 4 : 0) |
-                               (a->ent_loss_partial ? 8 : 0)};
-        int status = AECF_OK;
-        if (run_as_graph(key, user, [&](hipStream_t s) { return pool_forward_on(d, a, s); }, &status)) return status;
-    }
-    return pool_forward_on(d, a, user);
+    return pool_forward_on(d, a, (hipStream_t)stream);
 }
 
 int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream) {
-    hipStream_t user = (hipStream_t)stream;
-    if (d && a && !a->stage_events && !a->param_grads_event && !(a->flags & AECF_PRECISE) && graphs_enabled(d)) {
-        const GraphKey key{1, 0, d->batch, d->modalities, d->embed_dim, d->num_heads, d->dtype, d->mask_mode,
-                           (a->saved_prep ? 1 : 0) | (a->saved_v ? 2 : 0) | (a->d_entropy ? 4 : 0) | (a->grad_dtype << 4)};
-        int status = AECF_OK;
-        if (run_as_graph(key, user, [&](hipStream_t s) { return pool_backward_on(d, a, s); }, &status)) return status;
-    }
-    return pool_backward_on(d, a, user);
+    return pool_backward_on(d, a, (hipStream_t)stream);
 }
 
 int aecf_curriculum_mask_forward(int64_t rows, int32_t L, int32_t mode, int32_t min_active, float base_mask_prob,

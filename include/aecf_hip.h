@@ -12,28 +12,19 @@
  *  - the CALLER owns every buffer (including the workspace); the library never allocates or
  *    frees device memory, never retains a caller pointer past the call, never synchronises
  *    the stream and never throws.
- *  - every call only enqueues work on `stream` (a hipStream_t passed as void*): kernels, or -- for small
- *    aecf_pool_forward / aecf_pool_backward calls whose shape keeps coming back -- one executable HIP graph of those
- *    kernels (see "Library-owned state" below).
+ *  - every call only enqueues kernels on `stream` (a hipStream_t passed as void*) -- plain launches: a caller that is
+ *    capturing `stream` (a whole training step as one HIP graph) gets them as nodes of its own graph.
  *  - return value: AECF_OK (0) or a negative aecf_status.
  *  - dtype: AECF_BF16 or AECF_F32 for x / query / weights / y.  All statistics (attention weights, entropy, mask rate,
  *    saved probabilities) are float32 (optional copies in the activation dtype: aecf_pool_fwd_args.info_*).  Parameter
  *    gradients are float32, or bf16 when aecf_pool_bwd_args.grad_dtype asks for it (bf16 parameters: the float32 batch
  *    sums are rounded once, in the reduction kernel).
- *  - thread-safe: any thread may call with any stream of the current device; calls that replay a graph are serialised
- *    by one mutex.
- *  Library-owned state (all host-side, bounded, process-lifetime):
- *    * ONE debug knob, read once per process: the environment variable AECF_DEBUG = comma-separated tokens -- graph=0 / graph=1
- *      (force graph replay off / on), no_ws, no_gate_fusion, no_wide_tn, no_slab (route a shape through the kernels that serve the
- *      shapes the fast ones do not take: what the parity tests of those kernels use), fused_fwd (the one-kernel forward
- *      instead of the weight-stationary kernel pair), dx_reserve=N.  Unknown tokens are reported on stderr and ignored;
- *      unset = production behaviour;
- *    * one non-blocking capture stream per device, created on first use;
- *    * a cache of at most 8 hipGraphExec_t, least-recently-used evicted (hipGraphExecDestroy), keyed on
- *      (forward/backward, device, B, M, E, H, dtype, mask mode, which optional pointers are set).  A shape is captured
- *      and instantiated only from its 3rd sighting on, and only when B*M*E <= 2^25 (host-bound calls); larger calls and
- *      first sightings are plain kernel launches.  A graph holds no caller memory: its kernel arguments are rewritten
- *      (hipGraphExecUpdate) from the current call's pointers before every launch.
+ *  - thread-safe and stateless: any thread may call with any stream of the current device; the library keeps nothing between
+ *    calls.  The only process-wide input is ONE debug knob, read once: the environment variable AECF_DEBUG = comma-separated
+ *    tokens -- no_ws, no_gate_fusion, no_wide_tn, no_slab (route a shape through the kernels that serve the shapes the fast
+ *    ones do not take: what the parity tests of those kernels use), fused_fwd (the one-kernel forward instead of the
+ *    weight-stationary kernel pair), dx_reserve=N.  Unknown tokens are reported on stderr and ignored; unset = production
+ *    behaviour.
  */
 #ifndef AECF_HIP_H
 #define AECF_HIP_H
@@ -167,7 +158,7 @@ typedef struct aecf_pool_bwd_args {
     /* optional hipEvent_t (caller-created): recorded on `stream` as soon as ALL FIVE parameter gradients (dquery, dw_in,
      * db_in, dw_out, db_out) are final.  With it set the backward computes the input gradient dx LAST (otherwise it comes
      * before dW_v), so a data-parallel caller can run the gradients' all-reduce on another stream behind the dx kernel
-     * (aecf_amd/dp.py: GradOverlap).  stage_events are not recorded in this order of stages; graph replay is off.
+     * (aecf_amd/dp.py: GradOverlap).  stage_events are not recorded in this order of stages.
      * NULL = off. */
     void* param_grads_event;
 } aecf_pool_bwd_args;
