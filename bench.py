@@ -63,7 +63,7 @@ def settle(one_step, extra, by_clock):
     """SETTLE_STEPS + `extra` untimed steps and -- one rank only: with collectives in the step every rank has to run the same
     number -- at least until SETTLE_SECONDS after process start; returns the settle steps run."""
     n = 0
-    while n < SETTLE_STEPS or (by_clock and time.perf_counter() - T_PROCESS < SETTLE_SECONDS and n < 20000):
+    while n < SETTLE_STEPS or (by_clock and time.perf_counter() - T_PROCESS < SETTLE_SECONDS and n < 20000):   # (--settle-seconds)
         one_step()
         n += 1
     for _ in range(extra):
@@ -404,6 +404,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="one rank: the whole step captured once as a HIP graph and replayed (c4: static routing; the pool "
                          "configurations: forward + entropy loss + backward; meant for the host-bound shards)")
+    ap.add_argument("--settle-seconds", type=float, default=SETTLE_SECONDS,
+                    help="one rank: settle steps continue until this long after the device was first touched (0: the fixed "
+                         f"{SETTLE_STEPS} only -- what the profiling scripts pass, a counter pass records every launch)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = B per GPU fixed (default), strong = the config's B is the GLOBAL batch, sharded")
     ap.add_argument("--contrastive", action="store_true",
@@ -415,6 +418,7 @@ def main():
                          "after the backward)")
     ap.add_argument("--no-overlap", action="store_true", help="(default behaviour; kept for older command lines)")
     args = ap.parse_args()
+    globals()["SETTLE_SECONDS"] = args.settle_seconds
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))

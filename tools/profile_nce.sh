@@ -6,7 +6,7 @@ tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/ks_nce -o r -- python3 bench.py --config c3 --contrastive --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $out/ks_nce -o r -- python3 bench.py --settle-seconds 0 --config c3 --contrastive --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 python3 tools/kernel_stats_from_db.py $out/ks_nce/r_results.db $out/${tag}_c3nce_kernel_stats.csv | head -12
 rm -rf $out/ks_nce
 python3 bench.py --config c3 --contrastive --steps 50 --warmup 10 > $out/${tag}_c3nce_bench.json 2> /dev/null

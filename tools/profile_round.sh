@@ -8,14 +8,14 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out
 mkdir -p $out
 for cfg in c2 c3 c5; do
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pf_$cfg -o pmc -- python3 bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pw_$cfg -o pmc -- python3 bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pf_$cfg -o pmc -- python3 bench.py --settle-seconds 0 --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pw_$cfg -o pmc -- python3 bench.py --settle-seconds 0 --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
   python3 tools/traffic_from_pmc.py $out/pf_$cfg $out/pw_$cfg $cfg $out/${tag}_${cfg}_traffic.json > /dev/null
   cp $out/${tag}_${cfg}_traffic.json profiles/${tag}_${cfg}_traffic.json      # bench.py reads roofline.traffic from here
   rm -rf $out/pf_$cfg $out/pw_$cfg                       # (the raw counter databases: tens of MB each; gpurun returns at most 64 MiB)
   echo "traffic $cfg done"
 done
-rocprofv3 --kernel-trace --stats -d $out/ks -o r -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $out/ks -o r -- python3 bench.py --settle-seconds 0 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 python3 tools/kernel_stats_from_db.py $out/ks/r_results.db $out/${tag}_c2_kernel_stats.csv | head -16
 rm -rf $out/ks
 python3 bench.py --steps 50 --warmup 10 > $out/${tag}_c2_bench.json 2> /dev/null
