@@ -254,7 +254,8 @@ def cpu_baseline(cfg, seconds_budget=20.0):
     threads = min(trial, key=trial.get)
     torch.set_num_threads(threads)
     best, reps = best_of(one32, seconds_budget * 0.5, 20)
-    out = dict(value=n / best, unit="samples/s", cores=cores, threads=threads, logical_cpus=os.cpu_count(), kind="port",
+    # "cores" = the threads actually used (the contract's meaning); the machine's physical / logical counts beside it
+    out = dict(value=n / best, unit="samples/s", cores=threads, threads=threads, physical_cores=cores, logical_cpus=os.cpu_count(), kind="port",
                sample=f"{n} samples of the same [B,M={M},d={E}] workload, fp32, fwd (+ masking, entropy loss) + bwd, best of {reps}; "
                       f"thread sweep {({k: round(n / v) for k, v in trial.items()})} samples/s")
     try:      # bf16 leg (what torch's CPU bf16 kernels make of the same arithmetic), same step
