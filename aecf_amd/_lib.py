@@ -7,8 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
-                    c_uint8, c_void_p)
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # AECF_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build

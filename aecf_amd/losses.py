@@ -13,7 +13,6 @@ the exchange steps are ``dp.all_gather_rows`` (forward) and its reduce-scatter (
 """
 from __future__ import annotations
 
-import ctypes
 from typing import Optional
 
 import torch

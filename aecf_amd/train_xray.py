@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import dp
-from .xray import AECFModel, train_step
+from .xray import AECFModel
 
 
 def synthetic_split(n: int, num_classes: int, dim: int, seed: int, device, proto_seed: int = 1234):
