@@ -542,7 +542,9 @@ def main():
     # A fresh process needs ~25 steps (~15 ms) before its step time settles (tools/step_trend.py: 0.66, 0.65 ... 0.59 ms; 300 ms
     # of unrelated device work beforehand does not shorten it): SETTLE_STEPS untimed steps come first and are reported in the line
     # ("settle_steps", "effective_warmup"), then the W warm-up steps, then exactly K timed steps.
-    settled = settle(one_step, args.warmup, world == 1)
+    # the clock-based part of the settle only for host-bound call sizes: the device-bound configurations gain nothing from it
+    # and their first timed step after the barrier gets slower behind a long settle (1.0-1.5 ms against 0.66-0.8 ms)
+    settled = settle(one_step, args.warmup, world == 1 and B * M * E <= (1 << 25))
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (same stream)
     t0 = time.perf_counter()
