@@ -776,12 +776,28 @@ int aecf_l2norm_backward(int64_t n, int32_t d, int32_t dtype, const void* zn, co
     return launch_status();
 }
 
-size_t aecf_nce_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype) {
-    if (rows <= 0 || cols <= 0 || d <= 0) return 0;
-    if (nce_gemm_supported(dtype, d, 1.0f)) return nce_gemm_workspace_bytes(rows, cols, d);
-    if (nce_flash_supported(dtype, d)) return nce_flash_workspace_bytes(rows, cols, d);
+// bytes the generic (logits-in-memory) form of aecf_nce_fwd_bwd carves from its workspace
+static size_t nce_generic_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype) {
     const size_t es = esize(dtype);
     return align_up((size_t)rows * cols * 4) + align_up((size_t)rows * cols * es) + align_up((size_t)d * cols * es);
+}
+
+// The form aecf_nce_fwd_bwd takes depends on the TEMPERATURE as well (the tile GEMMs' constant-shift softmax needs
+// 1/T within the float32 exponent range), which this query does not see: it answers the LARGEST workspace any form
+// that can be selected for (d, dtype) needs, so the call never runs a form on a buffer sized for another one.
+size_t aecf_nce_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype) {
+    if (rows <= 0 || cols <= 0 || d <= 0) return 0;
+    size_t need = 0;
+    if (nce_gemm_supported(dtype, d, 1.0f)) need = nce_gemm_workspace_bytes(rows, cols, d);
+    if (nce_flash_supported(dtype, d)) {
+        const size_t f = nce_flash_workspace_bytes(rows, cols, d);      // (taken when the tile form refuses the temperature)
+        return f > need ? f : need;
+    }
+    if ((d % 64 == 0 && cols % 64 == 0) || need == 0) {
+        const size_t g = nce_generic_workspace_bytes(rows, cols, d, dtype);
+        if (g > need) need = g;
+    }
+    return need;
 }
 
 size_t aecf_nce_stream_workspace_bytes(int64_t rows, int64_t cols, int32_t d, int32_t dtype) {
@@ -811,7 +827,7 @@ int aecf_nce_fwd_bwd(int64_t rows, int64_t cols, int64_t row_offset, int32_t d, 
         return launch_status();
     }
     if (d % 64 != 0 || cols % 64 != 0) return AECF_ERR_UNSUPPORTED;
-    if (workspace_bytes < aecf_nce_workspace_bytes(rows, cols, d, dtype)) return AECF_ERR_WORKSPACE;
+    if (workspace_bytes < nce_generic_workspace_bytes(rows, cols, d, dtype)) return AECF_ERR_WORKSPACE;   // its OWN size
     hipStream_t s = (hipStream_t)stream;
     const size_t es = esize(dtype);
     char* ws = (char*)workspace;

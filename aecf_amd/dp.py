@@ -173,23 +173,32 @@ def flat_grad_alias(params: Iterable[torch.nn.Parameter]) -> Optional[torch.Tens
     return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(st, spans[0][0], (off - spans[0][0],))
 
 
-def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = True, fp32: bool = False):
+def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = True, fp32: Optional[bool] = None):
     """One collective for the gradients of ``params``: in place over their shared allocation when they alias one
     (see flat_grad_alias), else through a temporary flat copy.  Averages inside the collective (ReduceOp.AVG) when
     probe_avg_support found the backend takes it, else divides and sums.  The average is unweighted: with uneven
-    shards scale the local loss by shard_loss_scale.  ``fp32=True``: reduced-precision gradients (bf16 parameters) travel and
-    are summed as float32 and are rounded ONCE after the collective (a ring sum in bf16 rounds at every hop; each rank's own
-    rounding of its float32 batch sums to its bf16 ``p.grad`` has already happened and stays)."""
+    shards scale the local loss by shard_loss_scale.  ``fp32`` (default None = True whenever a gradient is bf16 / fp16):
+    reduced-precision gradients travel and are summed as float32 and are rounded ONCE after the collective -- a ring sum in
+    bf16 rounds at every hop, eight ranks' worth of it is the difference between 2e-2 and the single rounding the one-rank
+    step has (each rank's own rounding of its float32 batch sums to its bf16 ``p.grad`` has already happened and stays; at
+    4 E^2 + 5 E elements the float32 transport is 4 MB at d = 512, a latency-bound collective either way).  ``fp32=False``
+    keeps the gradients' own dtype on the wire."""
     params = [p for p in params if p.requires_grad and p.grad is not None]
     _, world = world_info(group)
     if world == 1 or not params:
         return
     flat = flat_grad_alias(params)
-    if fp32 and (flat is None or flat.dtype != torch.float32):
-        wide = torch.cat([p.grad.reshape(-1).float() for p in params])
+    reduced = any(p.grad.dtype in (torch.bfloat16, torch.float16) for p in params)
+    if fp32 is None:
+        fp32 = reduced
+    if fp32 and reduced:
+        wide = flat.float() if flat is not None else torch.cat([p.grad.reshape(-1).float() for p in params])
         dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
         if average:
             wide.div_(world)
+        if flat is not None:
+            flat.copy_(wide)                          # one rounding, in place over the allocation autograd holds
+            return
         off = 0
         for p in params:
             n = p.grad.numel()

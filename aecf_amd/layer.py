@@ -510,9 +510,12 @@ class CurriculumMasking(nn.Module):
         if tag is not None and not entropy.requires_grad and entropy.dtype in _DTYPES:
             # info['entropy'] of a fused pool forward, untouched: the kernel that wrote it left the per-block sums of
             # (nan_to_num(H) - target)^2 behind (aecf_pool_fwd_args.ent_loss_partial) -- one small launch adds them up
-            partial, n, target = tag
+            (partial, n, target), version = tag
             want = math.log(float(seq_len)) * self.entropy_target if seq_len > 1 else 0.0
-            if entropy.numel() == n and abs(want - target) <= 1e-6 * max(1.0, abs(want)):
+            # ... and UNTOUCHED is checked, not assumed: an in-place edit of the tensor (info['entropy'].clamp_(...), .mul_())
+            # or of any view of it moves the version counter they share, and the partial sums no longer describe the values:
+            # the full kernel below reads the tensor as it is now
+            if entropy._version == version and entropy.numel() == n and abs(want - target) <= 1e-6 * max(1.0, abs(want)):
                 loss = torch.empty(1, dtype=entropy.dtype, device=entropy.device)
                 _lib.check(_lib.load().aecf_entropy_loss_from_partials(n, _DTYPES[entropy.dtype], _ptr(partial), _ptr(loss),
                                                                        _stream()), "aecf_entropy_loss_from_partials")
@@ -768,7 +771,7 @@ class MultimodalAttentionPool(nn.Module):
                 ent = entropy.to(dt).unsqueeze(1)
                 if "ent_partial" in side and ent.dtype == entropy.dtype:
                     # this very tensor object carries the regulariser's partial sums (entropy_loss looks for them)
-                    ent._aecf_entropy_partials = side["ent_partial"]
+                    ent._aecf_entropy_partials = (side["ent_partial"], ent._version)
                 mask_info = {
                     'entropy': ent,
                     'mask_rate': mask_rate.unsqueeze(1),                             # float32 (ref :275)

@@ -159,6 +159,13 @@ def _sym_supported(z: torch.Tensor, temperature: float, cols: Optional[int] = No
     return True
 
 
+def _stream_form(z: torch.Tensor, cols: int) -> bool:
+    """True when the streaming InfoNCE kernels (no [rows, cols] logits in memory) exist for z's dtype and width."""
+    if z.dtype not in _DTYPES or not z.is_cuda:
+        return False
+    return _lib.load().aecf_nce_stream_workspace_bytes(z.shape[0], cols, z.shape[1], _DTYPES[z.dtype]) > 0
+
+
 class _LossDirection(torch.autograd.Function):
     """aecf_loss_fwd_bwd: ONE call for one InfoNCE direction (streaming form: no [rows, cols] logits) AND the entropy
     regulariser of the reference (CurriculumMasking.entropy_loss, ref aecf/AECFLayer.py:285-314) with their gradients
@@ -175,7 +182,12 @@ class _LossDirection(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         loss_rows, dq, dk = torch.empty(rows, **f32), torch.empty(rows, d, **f32), torch.empty(cols, d, **f32)
         ent_loss, dent = torch.empty(1, **f32), torch.empty(ent.numel(), **f32)
-        ws_bytes = lib.aecf_nce_workspace_bytes(rows, cols, d, _lib.AECF_BF16)
+        # this operator is the fallback of the symmetric tile-GEMM form (too little free memory for rows x cols bf16, or a
+        # temperature its constant-shift softmax does not take): hand over the STREAMING workspace (O(rows d)) where that
+        # kernel exists, so that the fallback never allocates more than the form it replaces
+        ws_bytes = lib.aecf_nce_stream_workspace_bytes(rows, cols, d, _lib.AECF_BF16)
+        if ws_bytes == 0:
+            ws_bytes = lib.aecf_nce_workspace_bytes(rows, cols, d, _lib.AECF_BF16)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.aecf_loss_fwd_bwd(rows, cols, row_offset, d, temperature, coef, _ptr(qc), _ptr(kc), _ptr(loss_rows),
                                          _ptr(dq), _ptr(dk), ent.numel(), last_seq_len, entropy_target, _ptr(ent), 1.0,
@@ -210,7 +222,7 @@ def contrastive_entropy_loss(za: torch.Tensor, zb: torch.Tensor, masking: Curric
         return contrastive_weight * l_nce + entropy_weight * l_ent.to(za.dtype)
     l_ab, l_ent = _LossDirection.apply(na, nb, entropy, 0, float(temperature), coef, int(seq_len),
                                        float(masking.entropy_target))
-    l_ba = _NceDirection.apply(nb, na, 0, float(temperature), coef)
+    l_ba = _NceDirection.apply(nb, na, 0, float(temperature), coef, _stream_form(nb, na.shape[0]))
     return contrastive_weight * (l_ab + l_ba) + entropy_weight * l_ent.to(za.dtype)
 
 
@@ -273,8 +285,11 @@ def info_nce(za: torch.Tensor, zb: torch.Tensor, temperature: float = 0.07, grou
         share, _ = _NceSymmetric.apply(na, nb_all, None, offset, float(temperature), coef, group, 2, 0.0)
     else:
         na_all = dp.all_gather_rows(na, group) if world > 1 else na
-        l_ab = _NceDirection.apply(na, nb_all, offset, float(temperature), coef)
-        l_ba = _NceDirection.apply(nb, na_all, offset, float(temperature), coef)
+        # (the symmetric form was refused -- memory, temperature or dtype: the streaming kernels where they exist, never
+        #  a second rows x cols allocation per direction)
+        low = _stream_form(na, b_all)
+        l_ab = _NceDirection.apply(na, nb_all, offset, float(temperature), coef, low)
+        l_ba = _NceDirection.apply(nb, na_all, offset, float(temperature), coef, low)
         share = l_ab + l_ba              # this rank's rows' share of the global objective
     if world == 1:
         return share

@@ -12,6 +12,7 @@ branch that owns it, zeros for rows with no modality).  Each is the other's back
 """
 from __future__ import annotations
 
+import copy
 import ctypes
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -270,14 +271,19 @@ class AECFModel(nn.Module):
 def _forward_static(self, image_features, text_features, has_a, has_b, return_info, mask_uniforms, generator):
     rows = image_features.size(0)
     a, b = has_a.bool(), has_b.bool()
-    enc_a = self.image_encoder(image_features)
-    enc_b = self.text_encoder(text_features)
+    # every row runs every branch here, so an ABSENT modality's features must not reach a weight: compact routing never
+    # touches them (presence = norm > 1e-6, ref :202-203, is False for NaN / Inf rows), and 0 * NaN = NaN would poison the
+    # batch sums of every parameter gradient.  Absent rows enter the encoders as zeros, branches are chosen with where.
+    zero = image_features.new_zeros(())
+    enc_a = self.image_encoder(torch.where(a.unsqueeze(1), image_features, zero))
+    enc_b = self.text_encoder(torch.where(b.unsqueeze(1), text_features, zero.to(text_features.dtype)))
     pairs = torch.stack([enc_a, enc_b], dim=1)                                   # [rows, 2, E] (what ref :213-214 stacks)
     pooled, pool_info = self.attention_pool(self.fusion_query.expand(rows, -1, -1), pairs, pairs, return_info=True,
                                             uniforms=mask_uniforms, generator=generator)
-    dt = enc_a.dtype
-    m_both, m_a, m_b = (a & b).to(dt).unsqueeze(1), (a & ~b).to(dt).unsqueeze(1), (b & ~a).to(dt).unsqueeze(1)
-    fused = self.fusion_proj(pooled.squeeze(1)) * m_both + self.image_proj(enc_a) * m_a + self.text_proj(enc_b) * m_b
+    both, only_a, only_b = (a & b).unsqueeze(1), (a & ~b).unsqueeze(1), (b & ~a).unsqueeze(1)
+    z = enc_a.new_zeros(())
+    fused = torch.where(both, self.fusion_proj(pooled.squeeze(1)), z) + torch.where(only_a, self.image_proj(enc_a), z) \
+        + torch.where(only_b, self.text_proj(enc_b), z)
     logits = self.classifier(fused)
     if not return_info:
         return logits
@@ -302,6 +308,11 @@ class GraphedTrainStep:
 
     def __init__(self, model: AECFModel, optimizer: torch.optim.Optimizer, criterion: nn.Module, batch: int, image_dim: int,
                  text_dim: int, num_classes: int, device, dtype=torch.float32, warmup: int = 3):
+        """Side effects, all deliberate: ``model.static_routing`` is set to True and stays so (the captured shapes depend on
+        it); the device generator advances by the warm-up and capture draws.  NOT a side effect: the warm-up and capture
+        steps run real optimisation steps on noise, so the model's parameters and buffers and the optimizer's state
+        (moments, step counters) are snapshotted before them and restored afterwards -- the first replay starts from exactly
+        the state the caller handed over."""
         model.static_routing = True
         self.model, self.optimizer, self.criterion = model, optimizer, criterion
         self.image = torch.zeros(batch, image_dim, device=device, dtype=dtype)
@@ -309,6 +320,9 @@ class GraphedTrainStep:
         self.labels = torch.zeros(batch, num_classes, device=device, dtype=dtype)
         self.image.normal_()
         self.text.normal_()
+        model_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        had_state = len(optimizer.state) > 0
+        opt_state = copy.deepcopy(optimizer.state_dict()) if had_state else None
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                        # warm-up on a side stream (allocator, lazily built state)
@@ -318,6 +332,22 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._step()
+        # restore IN PLACE (the graph holds the addresses of the parameters and of the optimizer's state tensors)
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(model_state[k])
+            if had_state:
+                saved = opt_state["state"]
+                live = optimizer.state_dict()["state"]
+                for idx, st in live.items():
+                    for name, val in st.items():
+                        if torch.is_tensor(val):
+                            val.copy_(saved[idx][name])
+            else:                                            # fresh optimizer: moments and step counters back to zero
+                for st in optimizer.state.values():
+                    for val in st.values():
+                        if torch.is_tensor(val):
+                            val.zero_()
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)

@@ -217,3 +217,45 @@ def test_all_reduce_grads_in_place_over_one_allocation():
         assert torch.allclose(torch.from_numpy(gb), torch.ones(4), atol=1e-6)
         assert torch.allclose(torch.from_numpy(ga2), da, atol=1e-6)
         assert torch.allclose(torch.from_numpy(gextra), torch.ones(4), atol=1e-6)
+
+
+def _bf16_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = (torch.randn(4096, generator=g) * 3.0).to(torch.bfloat16)          # one allocation, as the fused backward makes it
+        a, b = torch.nn.Parameter(torch.zeros(60, 64, dtype=torch.bfloat16)), torch.nn.Parameter(torch.zeros(256, dtype=torch.bfloat16))
+        ga, gb = flat.split([3840, 256])
+        a.grad, b.grad = ga.view(60, 64), gb
+        ptr = a.grad.data_ptr()
+        mine = flat.float().clone()
+        dp.all_reduce_grads([a, b])                                # default: float32 on the wire, ONE rounding afterwards
+        q.put((rank, mine.numpy(), a.grad.float().numpy().reshape(-1), b.grad.float().numpy(), a.grad.data_ptr() == ptr,
+               a.grad.dtype == torch.bfloat16))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bf16_gradients_travel_as_float32_by_default():
+    """bf16 parameter gradients averaged in bf16 round at every hop of a ring; the default transport is
+    float32 with one rounding of the mean, in place over the allocation the backward wrote."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    mean = (torch.from_numpy(res[0][1]) + torch.from_numpy(res[1][1])) / 2        # exact in float32 for two bf16 addends
+    want = mean.to(torch.bfloat16).float()
+    for rank, _, ga, gb, in_place, is_bf16 in res:
+        assert in_place and is_bf16
+        got = torch.cat([torch.from_numpy(ga), torch.from_numpy(gb)])
+        assert torch.equal(got, want), rank

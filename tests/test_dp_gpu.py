@@ -115,7 +115,7 @@ def _worker(rank, world, port, backend, dtype, q):
         (((oa.float() * dy[lo:mid].to(dev).float()).sum() + (ob.float() * dy[mid:hi].to(dev).float()).sum()) / B * world).backward()
         dp.all_reduce_grads(params)
         torch.cuda.synchronize()
-        tol2 = 1e-5 if dtype == torch.float32 else 2e-2       # (sum of two reduced gradients vs reduced sum: one more rounding)
+        tol2 = 1e-5 if dtype == torch.float32 else 1e-2       # (sum of two reduced gradients vs reduced sum: one more rounding)
         for a_, p in zip(two, params):
             err = (a_.float() - p.grad.float()).abs().max().item() / max(p.grad.float().abs().max().item(), 1e-12)
             assert err < tol2, err
@@ -124,12 +124,12 @@ def _worker(rank, world, port, backend, dtype, q):
         with overlap:
             from aecf_amd import layer as _layer
             assert _layer._param_grads_hook is None
-        # float32 transport of reduced-precision gradients: equal to the plain collective up to one rounding
+        # bf16 transport (fp32=False) against the default float32 transport (`plain`)
         if dtype == torch.bfloat16:
             for p in params:
                 p.grad = None
             _run_shard(query, pool, x[lo:hi], dy[lo:hi], u, dev, float(world))
-            dp.all_reduce_grads(params, fp32=True)
+            dp.all_reduce_grads(params, fp32=False)        # the gradients' own dtype on the wire: within a rounding or two of the default
             torch.cuda.synchronize()
             for a_, p in zip(plain, params):
                 err = (a_.float() - p.grad.float()).abs().max().item() / max(a_.float().abs().max().item(), 1e-12)
@@ -171,7 +171,10 @@ def test_two_ranks_equal_one_rank(dtype):
     u = dp.global_uniforms(B, 1, M, seed=77, device=dev)
     out, masked, dx = _run_shard(query, pool, x, dy, u, dev, 1.0)
     torch.cuda.synchronize()
-    tol = 2e-5 if dtype == torch.float32 else 2e-2       # bf16: parameter gradients are rounded to bf16 per rank
+    # bf16: each rank rounds its float32 batch sums to bf16 once, the collective moves and sums them as float32 (the default
+    # of all_reduce_grads for reduced-precision gradients) and rounds the mean once: at most three bf16 roundings against the
+    # one-rank gradient (which carries one itself) -- 5e-3 of the largest element, not the 2e-2 a bf16 ring sum needed
+    tol = 2e-5 if dtype == torch.float32 else 5e-3
     for rank, lo, hi, o_r, m_r, dx_r, grads, _ in res:
         assert torch.equal(torch.from_numpy(o_r), out[lo:hi].float().cpu())           # per-sample outputs bit-equal
         assert torch.equal(torch.from_numpy(m_r), masked[lo:hi].float().cpu())        # masks independent of N

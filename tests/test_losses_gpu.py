@@ -187,3 +187,74 @@ def test_contrastive_plus_entropy_loss_in_one_call():
     assert abs(float(fused) - float(sep)) < 1e-3 * abs(float(sep))
     assert rel_err(ga.float(), za.grad.float()) < 1e-5 and rel_err(gb.float(), zb.grad.float()) < 1e-5
     assert rel_err(ge, ent.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,d", [(1024, 192), (1024, 512), (320, 320)])
+def test_info_nce_low_temperature_takes_a_form_sized_for_itself(n, d):
+    """CLIP-style T = 0.02 is below what the tile GEMMs' constant-shift softmax takes (T >= 0.025): the call falls through to
+    the streaming kernels (d in their set) or to the logits-in-memory form (d = 192, 320).  ADVICE r3 (high): that form
+    used to check its workspace against the tile-GEMM size and write past the buffer.  Guard bytes behind the workspace the
+    C ABI is handed must survive, and the loss must match float32 math."""
+    import ctypes
+    from aecf_amd import _lib, losses
+    from aecf_amd.layer import _ptr, _stream
+    dev = torch.device("cuda:0")
+    T = 0.02
+    g = torch.Generator().manual_seed(n + d)
+    za = torch.randn(n, d, generator=g).to(torch.bfloat16)
+    zb = (za.float() * 0.7 + 0.5 * torch.randn(n, d, generator=g)).to(torch.bfloat16)
+    # (1) the public operator against float32 math on the same bf16 inputs
+    a = za.to(dev).requires_grad_(True)
+    b = zb.to(dev).requires_grad_(True)
+    loss = losses.info_nce(a, b, temperature=T)
+    loss.backward()
+    af = za.float().to(dev).requires_grad_(True)
+    bf = zb.float().to(dev).requires_grad_(True)
+    na, nb = torch.nn.functional.normalize(af, dim=-1), torch.nn.functional.normalize(bf, dim=-1)
+    lg = na @ nb.t() / T
+    tgt = torch.arange(n, device=dev)
+    want = 0.5 * (torch.nn.functional.cross_entropy(lg, tgt) + torch.nn.functional.cross_entropy(lg.t(), tgt))
+    want.backward()
+    assert abs(float(loss) - float(want)) < 3e-2 * max(1.0, abs(float(want)))
+    assert rel_err(a.grad.float().cpu(), af.grad.cpu()) < 0.1
+    # (2) the C ABI: a buffer of exactly aecf_nce_workspace_bytes followed by guard bytes
+    lib = _lib.load()
+    q = losses.l2_normalize(za.to(dev)).detach().contiguous()
+    k = losses.l2_normalize(zb.to(dev)).detach().contiguous()
+    need = lib.aecf_nce_workspace_bytes(n, n, d, _lib.AECF_BF16)
+    guard = 1 << 20
+    buf = torch.full((need + guard,), 0x5A, dtype=torch.uint8, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    lr, dq, dk = torch.empty(n, **f32), torch.empty(n, d, **f32), torch.empty(n, d, **f32)
+    _lib.check(lib.aecf_nce_fwd_bwd(n, n, 0, d, _lib.AECF_BF16, T, 0.5 / n, _ptr(q), _ptr(k), _ptr(lr), _ptr(dq), _ptr(dk),
+                                    _ptr(buf), need, _stream()), "aecf_nce_fwd_bwd")
+    torch.cuda.synchronize()
+    assert bool((buf[need:] == 0x5A).all()), "the call wrote past the workspace it was given"
+    assert torch.isfinite(lr).all() and torch.isfinite(dq).all() and torch.isfinite(dk).all()
+    # one byte less than the form's own need is refused, not overrun
+    if need > 4096:
+        st = lib.aecf_nce_fwd_bwd(n, n, 0, d, _lib.AECF_BF16, T, 0.5 / n, _ptr(q), _ptr(k), _ptr(lr), _ptr(dq), _ptr(dk),
+                                  _ptr(buf), 4096, _stream())
+        assert st != 0
+
+
+def test_sym_memory_guard_falls_back_to_the_streaming_form(monkeypatch):
+    """when the symmetric form is refused for memory, the fallbacks must not allocate rows x cols either."""
+    from aecf_amd import losses
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    n, d = 512, 256
+    za = torch.randn(n, d, generator=g).to(torch.bfloat16).to(dev)
+    zb = (za.float() * 0.7 + 0.5 * torch.randn(n, d, generator=g).to(dev)).to(torch.bfloat16)
+    want = float(losses.info_nce(za, zb, temperature=0.1))
+    monkeypatch.setattr(losses, "_sym_supported", lambda *a, **k: False)
+    seen = []
+    real = losses._NceDirection.apply
+
+    def spy(*args):
+        seen.append(bool(args[5]) if len(args) > 5 else False)
+        return real(*args)
+    monkeypatch.setattr(losses._NceDirection, "apply", staticmethod(spy))
+    got = float(losses.info_nce(za, zb, temperature=0.1))
+    assert seen == [True, True], f"the fallback must select the streaming kernels (low_memory), saw {seen}"
+    assert abs(got - want) < 2e-2 * max(1.0, abs(want))

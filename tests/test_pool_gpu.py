@@ -744,6 +744,33 @@ def test_entropy_loss_from_the_forward_partial_sums(dtype, B, M, E, H):
     assert abs(float(other) - float(plain)) > 1e-4
 
 
+@pytest.mark.parametrize("edit", ["mul_", "clamp_", "view_fill_"])
+def test_entropy_partials_are_dropped_after_an_in_place_edit(edit):
+    """info['entropy'] carries the forward's partial sums as an attribute; an in-place edit of the tensor
+    (or of a view of it) must not leave entropy_loss on the stale sums -- the tag records the version counter."""
+    import aecf_amd
+    dev = _dev()
+    torch.manual_seed(9)
+    B, M, E, H = 3000, 3, 512, 8
+    query, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=0.3, num_heads=H)
+    pool = pool.to(dev, torch.float32).train()
+    x = torch.randn(B, M, E, device=dev) * torch.linspace(0.5, 3.0, M, device=dev).view(1, M, 1)
+    out, info = pool(query.detach().to(dev).expand(B, -1, -1), x, return_info=True)
+    ent = info["entropy"]
+    cm = pool.curriculum_masking
+    before = float(cm.entropy_loss(ent))
+    if edit == "mul_":
+        ent.mul_(2.0)
+    elif edit == "clamp_":
+        ent.clamp_(max=0.3)
+    else:
+        ent.view(-1)[: B // 2].fill_(0.0)             # through a view: the version counter is shared
+    after = float(cm.entropy_loss(ent))
+    want = float(cm.entropy_loss(ent.clone()))       # (a copy carries no tag: the stand-alone operator)
+    assert abs(after - want) <= 1e-6 * max(1.0, abs(want))
+    assert abs(after - before) > 1e-5
+
+
 @pytest.mark.parametrize("E,H,dtype,tol", [(40, 2, torch.float32, 1e-5), (100, 4, torch.float32, 1e-5), (24, 3, torch.float32, 1e-5),
                                            (100, 4, torch.bfloat16, 1.2e-2), (72, 2, torch.bfloat16, 1.2e-2)])
 def test_embed_sizes_no_kernel_tiles_are_served_by_head_padding(E, H, dtype, tol):

@@ -61,13 +61,14 @@ def test_graphed_train_step_equals_eager_steps():
     crit = torch.nn.BCEWithLogitsLoss()
     opt_e = torch.optim.AdamW(eager.parameters(), lr=1e-3, weight_decay=0.01)
     opt_g = torch.optim.AdamW(graphed_model.parameters(), lr=1e-3, weight_decay=0.01, capturable=True)
-    state = copy.deepcopy(graphed_model.state_dict())
+    # the constructor's warm-up and capture steps run on noise; it restores parameters and optimizer state itself
     step = GraphedTrainStep(graphed_model, opt_g, crit, 64, 512, 512, 15, dev, warmup=3)
-    graphed_model.load_state_dict(state)              # undo the warm-up / capture steps: same start as the eager model
+    for p, q in zip(eager.parameters(), graphed_model.parameters()):
+        assert torch.equal(p.detach(), q.detach())
     for st in opt_g.state.values():
         for k, v in st.items():
             if torch.is_tensor(v):
-                v.zero_()
+                assert float(v.abs().max()) == 0.0, k
     losses_e, losses_g = [], []
     for k in range(6):
         image, text, labels = _batch(64, dev, 10 + k)
@@ -93,3 +94,84 @@ def test_bench_pool_step_replays_as_one_graph():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["graph_replay"] is True and line["value"] > 0
+
+
+def test_graphed_step_keeps_a_trained_optimizers_state():
+    """A GraphedTrainStep built around an optimizer that has already stepped gives its moments and step counters back."""
+    from aecf_amd.xray import AECFModel, GraphedTrainStep, train_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    model = AECFModel(512, 512, 15).to(dev).train()
+    crit = torch.nn.BCEWithLogitsLoss()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, capturable=True)
+    for k in range(2):
+        image, text, labels = _batch(64, dev, 40 + k)
+        train_step(model, opt, crit, image, text, labels)
+    before_p = [p.detach().clone() for p in model.parameters()]
+    before_s = copy.deepcopy(opt.state_dict()["state"])
+    GraphedTrainStep(model, opt, crit, 64, 512, 512, 15, dev, warmup=2)
+    for p, q in zip(before_p, model.parameters()):
+        assert torch.equal(p, q.detach())
+    after_s = opt.state_dict()["state"]
+    for idx, st in before_s.items():
+        for name, val in st.items():
+            if torch.is_tensor(val):
+                assert torch.equal(val, after_s[idx][name]), (idx, name)
+
+
+def test_graphed_step_with_curriculum_masking_and_modality_draws():
+    """Capture with the random parts ON (curriculum masking in the pool, missing-modality training draws): the replayed steps
+    must draw fresh randomness per replay (the device generator's offset advances) and train -- losses finite, not
+    constant, parameters moving; and a replay sequence is reproducible from the same seed."""
+    from aecf_amd.xray import AECFModel, GraphedTrainStep
+    dev = torch.device("cuda:0")
+
+    def run(seed):
+        torch.manual_seed(seed)
+        model = AECFModel(512, 512, 15).to(dev).train()
+        model.toggle_curriculum(True)
+        crit = torch.nn.BCEWithLogitsLoss()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, capturable=True)
+        start = [p.detach().clone() for p in model.parameters()]
+        step = GraphedTrainStep(model, opt, crit, 64, 512, 512, 15, dev, warmup=2)
+        torch.cuda.manual_seed(seed + 100)            # (the constructor's draws advanced the generator: pin the replays' stream)
+        out = []
+        for k in range(5):
+            image, text, labels = _batch(64, dev, 20 + k)
+            out.append(float(step(image, text, labels)))
+        moved = max(float((p.detach() - q).abs().max()) for p, q in zip(model.parameters(), start))
+        return out, moved
+
+    a, moved = run(11)
+    b, _ = run(11)
+    assert all(torch.isfinite(torch.tensor(a))) and moved > 0
+    assert len(set(round(v, 6) for v in a)) > 1
+    assert a == b, (a, b)
+
+
+def test_static_routing_ignores_non_finite_features_of_absent_modalities():
+    """a row whose ABSENT modality holds NaN / Inf is excluded by compact routing (presence = norm > 1e-6 is
+    False for it); static routing must give the same logits and finite, equal gradients -- select, not multiply by 0."""
+    from aecf_amd.xray import AECFModel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    compact = AECFModel(512, 512, 15).to(dev).train()
+    for m in compact.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    static = copy.deepcopy(compact)
+    static.static_routing = True
+    image, text, labels = _batch(96, dev, 7)
+    image[5] = float("nan")                            # absent image (a NaN norm is not > 1e-6), text present
+    text[8] = float("nan")                             # absent text
+    crit = torch.nn.BCEWithLogitsLoss()
+    la = compact(image, text)
+    lb = static(image, text)
+    assert torch.isfinite(lb).all()
+    assert rel_err(lb.detach().cpu(), la.detach().cpu()) < 1e-5
+    crit(la, labels).backward()
+    crit(lb, labels).backward()
+    for (n, p), q in zip(compact.named_parameters(), static.parameters()):
+        assert torch.isfinite(q.grad).all(), n         # static routing feeds absent rows to the encoders as zeros
+        if "encoder" not in n:                         # (compact routing, like the reference, runs the encoders on every row:
+            assert rel_err(q.grad.cpu(), p.grad.cpu()) < 2e-5, n      #  its encoder weight gradients are NaN here)
