@@ -7,16 +7,17 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # AECF_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
 LIB_PATH = os.environ.get("AECF_LIB_PATH") or os.path.join(_HERE, "lib", "libaecf_hip.so")
 
-AECF_ABI_VERSION = 7
+AECF_ABI_VERSION = 8
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_PRECISE = 1
+AECF_DRAW_UNIFORMS = 2
 AECF_FWD_STAGES = 4
 AECF_BWD_STAGES = 8
 
@@ -53,6 +54,7 @@ class PoolFwdArgs(Structure):
         ("info_mask_rate", c_void_p), ("saved_prep", c_void_p),
         ("info_target_entropy", c_void_p), ("target_entropy_value", c_float), ("flags", c_int32),
         ("ent_loss_partial", c_void_p),
+        ("philox_seed", c_uint64), ("philox_offset", c_uint64), ("philox_threads", c_uint32), ("ent_loss", c_void_p),
     ]
 
 
@@ -101,6 +103,8 @@ _SYMBOLS = [
     ("aecf_pool_prep_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_wants_saved_v", c_int, [POINTER(PoolDesc)]),
     ("aecf_pool_precise_workspace_bytes", c_size_t, [POINTER(PoolDesc), c_int]),
+    ("aecf_philox_uniforms", c_int, [c_int64, c_uint64, c_uint64, c_uint32, c_void_p, c_void_p]),
+    ("aecf_philox_host", c_float, [c_uint64, c_uint64, c_uint32, c_int64, c_void_p]),
     ("aecf_pool_forward", c_int, [POINTER(PoolDesc), POINTER(PoolFwdArgs), c_void_p]),
     ("aecf_pool_backward", c_int, [POINTER(PoolDesc), POINTER(PoolBwdArgs), c_void_p]),
     ("aecf_curriculum_mask_forward", c_int,

@@ -247,7 +247,9 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     if (precise && a->workspace_bytes < precise_fwd_layout(d).total) return AECF_ERR_WORKSPACE;
     if (!a || !a->x || !a->query || !a->w_in || !a->w_out || !a->y || !a->attn_w || !a->saved_probs || !a->workspace)
         return AECF_ERR_NULL_POINTER;
-    if (d->mask_mode == 1 && !a->uniforms) return AECF_ERR_NULL_POINTER;
+    const bool draw = d->mask_mode == 1 && !a->uniforms && (a->flags & AECF_DRAW_UNIFORMS);
+    if (d->mask_mode == 1 && !a->uniforms && !draw) return AECF_ERR_NULL_POINTER;
+    if (draw && (a->philox_threads == 0 || a->philox_threads % 256 != 0 || a->philox_offset % 4 != 0)) return AECF_ERR_BAD_DIMS;
     const FwdWs L = fwd_layout(d);
     if (a->workspace_bytes < L.total) return AECF_ERR_WORKSPACE;
     char* ws = (char*)a->workspace;
@@ -292,6 +294,7 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     g.i_target = d->mask_mode == 1 ? a->info_target_entropy : nullptr; g.target_value = a->target_entropy_value;
     g.B = d->batch; g.M = M; g.E = E; g.H = H;
     g.mask = make_mask_cfg(d->mask_mode, d->min_active, d->base_mask_prob, d->entropy_target, d->eps, M);
+    if (draw) { g.ph.seed = a->philox_seed; g.ph.offset = a->philox_offset; g.ph.threads = a->philox_threads; }
     GemmNtArgs v;
     v.a = a->x; v.w = (const char*)a->w_in + (size_t)2 * E * E * es;
     v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
@@ -309,6 +312,7 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
         if (d->mask_mode == 1 && a->ent_loss_partial) {
             if (a->info_entropy) launch_entropy_partials(d->dtype, d->batch, a->target_entropy_value, a->info_entropy, a->ent_loss_partial, s);
             else if (a->entropy) launch_entropy_partials(AECF_F32, d->batch, a->target_entropy_value, a->entropy, a->ent_loss_partial, s);
+            if (a->ent_loss) launch_entropy_from_partials(d->dtype, d->batch, a->ent_loss_partial, a->ent_loss, s);
         }
         mark(ev, 3, s);
         mark(ev, 4, s);
@@ -349,7 +353,16 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
         return launch_status();
     }
     if (frag) y.w_frag = ws + L.wo_frag;
+    // the entropy regulariser's final sum rides in the out-projection launch where the weight-stationary kernel runs it
+    // (its first block adds the statistics kernel's partial sums: no launch of its own), else it is one small launch
+    const bool want_loss = ent_partial && a->ent_loss;
+    const bool loss_rides = want_loss && d->dtype == AECF_BF16 && !env_no_ws() && gemm_ws_supported(y);
+    if (loss_rides) {
+        y.ent_partial = ent_partial; y.ent_nblk = (int)((d->batch + 255) / 256); y.ent_inv_n = 1.0f / (float)d->batch;
+        y.ent_loss = a->ent_loss;
+    }
     launch_gemm_nt(d->dtype, y, s);
+    if (want_loss && !loss_rides) launch_entropy_from_partials(d->dtype, d->batch, ent_partial, a->ent_loss, s);
     mark(ev, 4, s);
     return launch_status();
 }
@@ -478,7 +491,14 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     // block, and the collective's workgroups could only start as those retire (AECF_DX_RESERVE_CUS, default 16 of 256;
     // UNMEASURED here -- no multi-GPU box -- it costs the dx kernel ~6 % and is meant to buy the all-reduce its overlap)
     if (dx_last) g2.cu_budget = 256 - env_dx_reserve();
-    auto run_dx = [&]() { if (!(d->dtype == AECF_BF16 && launch_dx_ws(g2, s))) launch_bwd_g(d->dtype, g2, true, s); };
+    // where the weight-stationary dx kernel runs between the score gradient and the finalize launch, it also adds up the
+    // u slabs (a side job of its weight prologue): the finalize launch then depends on no reduction launch
+    bool u_reduced = false;
+    if (dsu_chunks && !dx_last) { g2.u_slab_in = (const float*)(ws + L.u_slab); g2.u_out = u; g2.u_nslab = dsu_chunks; }
+    auto run_dx = [&]() {
+        if (d->dtype == AECF_BF16 && launch_dx_ws(g2, s)) { u_reduced = g2.u_slab_in != nullptr; return; }
+        launch_bwd_g(d->dtype, g2, true, s);
+    };
     if (!dx_last) run_dx();
     mark(ev, 5, s);
 
@@ -489,6 +509,11 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     t2.hd = hd; t2.Ej = 0; t2.splits = L.splits; t2.rows_per_split = L.rows_per_split; t2.pooled = 1;
     t2.u_splits = L.u_splits; t2.u_rows_per_split = L.u_rows_per_split;
     t2.parts = 1;
+    // dq' = scale W_k u (every remaining gradient of the tail hangs on it) rides in this launch where u is already reduced
+    DqpJob dq;
+    dq.w_k = (const char*)a->w_in + (size_t)E * E * es; dq.u = u; dq.dqp = (float*)(ws + L.dqp); dq.scale = scale; dq.E = E; dq.hd = hd;
+    const bool dqp_rides = u_reduced && d->dtype == AECF_BF16;
+    if (dqp_rides) t2.dq = dq;
     launch_gemm_tn(d->dtype, t2, s);
     mark(ev, 6, s);
     if (!dsu_chunks) {
@@ -508,13 +533,19 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = (char*)a->dw_in + (size_t)2 * E * E * gsz; rs.n[2] = (int64_t)E * E;
     rs.src[3] = (const float*)(ws + L.cs_v);   rs.dst[3] = (char*)a->db_in + (size_t)2 * E * gsz;  rs.n[3] = E;
     rs.src[4] = (const float*)(ws + L.u_slab); rs.dst[4] = u;                                      rs.n[4] = (int64_t)H * E;
-    launch_reduce_segments(rs, s);
+    if (!u_reduced) {                                                  // u first, on its own: every finalize block reads all of it
+        ReduceSegs ru = rs;
+        for (int i = 0; i < 4; ++i) ru.n[i] = 0;
+        launch_reduce_segments(ru, s);
+    }
+    rs.n[4] = 0;
+    if (!dqp_rides) launch_dqp(d->dtype, dq, s);
 
     FinalizeArgs f;
     f.w_in = a->w_in; f.query = a->query; f.qs = qs; f.u = u; f.dqp = (float*)(ws + L.dqp);
     f.dq_part = (float*)(ws + L.dq_part); f.dw_in = a->dw_in;
     f.db_in = a->db_in; f.dquery = a->dquery; f.E = E; f.H = H; f.hd = hd; f.scale = scale; f.grad_bf16 = gb;
-    launch_finalize(d->dtype, f, s);
+    launch_finalize_all(d->dtype, f, rs, s);
     if (dx_last) {
         (void)hipEventRecord((hipEvent_t)a->param_grads_event, s);
         run_dx();
@@ -532,6 +563,7 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
 //   dx_reserve=N        CUs the dx kernel leaves free when it runs beside a collective (default 16, 0..128)
 struct EnvSwitches {
     bool no_ws = false, no_gate_fusion = false, no_wide_tn = false, no_slab = false, fused_fwd = false;
+    int dsu_var = 2;
     int dx_reserve = 16;
 };
 const EnvSwitches& env_switches() {
@@ -551,6 +583,7 @@ const EnvSwitches& env_switches() {
             else if (tok == "no_wide_tn") v.no_wide_tn = true;
             else if (tok == "no_slab") v.no_slab = true;
             else if (tok == "fused_fwd") v.fused_fwd = true;
+            else if (tok.rfind("dsu_var=", 0) == 0) v.dsu_var = atoi(tok.c_str() + 8);
             else if (tok.rfind("dx_reserve=", 0) == 0) {
                 const int n = atoi(tok.c_str() + 11);
                 if (n >= 0 && n <= 128) v.dx_reserve = n;
@@ -571,6 +604,7 @@ namespace aecf {
 bool env_no_ws() { return env_switches().no_ws; }
 bool env_no_wide_tn() { return env_switches().no_wide_tn; }
 bool env_no_slab() { return env_switches().no_slab; }
+int env_dsu_var() { return env_switches().dsu_var; }
 }  // namespace aecf
 
 extern "C" {
@@ -637,6 +671,29 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
     if (!q || !k || !v || !probs || !dout || !dq || !dk || !dv) return AECF_ERR_NULL_POINTER;
     launch_sdpa_bwd(dtype, B, S, T, E, scale, q, k, v, probs, dout, dq, dk, dv, (hipStream_t)stream);
     return launch_status();
+}
+
+int aecf_philox_uniforms(int64_t n, uint64_t seed, uint64_t offset, uint32_t threads, float* out, void* stream) {
+    if (n <= 0 || threads == 0 || threads % 256 != 0 || offset % 4 != 0) return AECF_ERR_BAD_DIMS;
+    if (!out) return AECF_ERR_NULL_POINTER;
+    PhiloxDraw ph;
+    ph.seed = seed; ph.offset = offset; ph.threads = threads;
+    launch_philox_uniforms(n, ph, out, (hipStream_t)stream);
+    return launch_status();
+}
+
+float aecf_philox_host(uint64_t seed, uint64_t offset, uint32_t threads, int64_t element, uint32_t* raw) {
+    PhiloxDraw ph;
+    ph.seed = seed; ph.offset = offset; ph.threads = threads ? threads : 256;
+    if (raw) {
+        const unsigned long long T = ph.threads, per = 4ull * T;
+        const unsigned long long it = (unsigned long long)element / per, rem = (unsigned long long)element - it * per;
+        const unsigned long long idx = rem - (rem / T) * T, ctr = ph.offset / 4ull + it;
+        unsigned int c[4] = {(unsigned int)ctr, (unsigned int)(ctr >> 32), (unsigned int)idx, (unsigned int)(idx >> 32)};
+        philox4x32_10(c, (unsigned int)seed, (unsigned int)(seed >> 32));
+        for (int i = 0; i < 4; ++i) raw[i] = c[i];
+    }
+    return philox_uniform_at(ph, element);
 }
 
 int aecf_entropy_loss_from_partials(int64_t n, int32_t dtype, const float* partial, void* loss, void* stream) {

@@ -132,6 +132,89 @@ __device__ __forceinline__ float reduce_r16(float v) {
 __device__ __forceinline__ float reduce_wave(float v) { return reduce_lg(reduce_r16(v)); }
 
 // ---------------------------------------------------------------------------------------------
+// dq'[j] = scale * W_k[j,:] . u[h(j)]  (the query-side gradient every remaining piece of the backward's tail hangs on:
+// dW_q = dq' (x) q, db_q = dq', dquery = W_q^T dq').  E dots of length E against the REDUCED u: small enough to ride as a side
+// job in the weight-gradient launch that runs between the kernel that reduces u and the finalize launch (rows dealt over the
+// launch's blocks, one wave per row), so that the finalize launch has no dependent chain inside it.
+struct DqpJob {
+    const void* w_k = nullptr;    // [E,E] dtype (rows j); null = off
+    const float* u = nullptr;     // [H,E] reduced
+    float* dqp = nullptr;         // [E]
+    float scale = 0.f;
+    int E = 0, hd = 1;
+};
+
+template <typename T>
+__device__ __forceinline__ void dqp_rows(const DqpJob& q, int block, int nblocks) {
+    using X = Tr<T>;
+    const int per = (q.E + nblocks - 1) / nblocks;
+    const int j0 = block * per, j1 = (j0 + per) < q.E ? (j0 + per) : q.E;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (int)blockDim.x >> 6;
+    for (int j = j0 + w; j < j1; j += nw) {                        // (wave-uniform bounds: whole waves take the butterfly)
+        const float* u = q.u + (int64_t)(j / q.hd) * q.E;
+        const typename X::elem* wr = reinterpret_cast<const typename X::elem*>(q.w_k) + (int64_t)j * q.E;
+        float a = 0.f;
+        for (int c = lane * 8; c < q.E; c += 512) {
+            float wv[8];
+            X::load4(wr + c, wv);
+            X::load4(wr + c + 4, wv + 4);
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(u + c), u1 = *reinterpret_cast<const f32x4*>(u + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = fmaf(wv[e], u0[e], a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = fmaf(wv[4 + e], u1[e], a);
+        }
+        a = reduce_wave(a);
+        if (lane == 0) q.dqp[j] = a * q.scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The Bernoulli draw of ref aecf/AECFLayer.py:204 without a uniforms tensor: the statistics kernel evaluates, per weight
+// element, the SAME counter-based generator call that `torch.rand(n, device=...)` makes for that element, so a step that
+// lets the kernel draw (aecf_pool_fwd_args.flags & AECF_DRAW_UNIFORMS) and a step that passes `uniforms = torch.rand(...)`
+// from the same generator state see the same masks bit for bit, and the generator advances by the same offset.
+//   torch (ATen/native/cuda/DistributionTemplates.h: distribution_elementwise_grid_stride_kernel, unroll 4) launches
+//   T = 256 * grid threads; thread idx seeds Philox4x32-10 with (seed, subsequence = idx, offset) and per grid-stride
+//   iteration draws ONE 4-vector; component ii of iteration `it` goes to element  li = idx + T * ii + 4 T * it.
+//   rocRAND's engine: counter = {offset / 4 + it (64-bit: x, y), subsequence (64-bit: z, w)}, key = seed; value =
+//   2^-32 + v * 2^-32  in (0, 1], and torch maps 1.0 to 0.0 ("reverse the bounds").
+// Philox4x32-10 itself is Salmon et al., SC'11 (Random123); known-answer vectors in tests/test_host_cpu.py.
+struct PhiloxDraw {
+    unsigned long long seed = 0, offset = 0;      // the generator's (seed, philox offset) BEFORE this draw
+    unsigned int threads = 0;                     // T of the torch launch this draw replaces (0 = drawing off)
+};
+
+__device__ __host__ __forceinline__ void philox4x32_10(unsigned int c[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (unsigned int)p1;
+        c[3] = (unsigned int)p0;
+        c[0] = n0;
+        c[2] = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// the float32 uniform torch.rand puts at linear element li
+__device__ __host__ __forceinline__ float philox_uniform_at(const PhiloxDraw& ph, long long li) {
+    const unsigned long long T = ph.threads, per = 4ull * T;
+    const unsigned long long it = (unsigned long long)li / per, rem = (unsigned long long)li - it * per;
+    const unsigned int ii = (unsigned int)(rem / T);
+    const unsigned long long idx = rem - (unsigned long long)ii * T;
+    const unsigned long long ctr = ph.offset / 4ull + it;
+    unsigned int c[4] = {(unsigned int)ctr, (unsigned int)(ctr >> 32), (unsigned int)idx, (unsigned int)(idx >> 32)};
+    philox4x32_10(c, (unsigned int)ph.seed, (unsigned int)(ph.seed >> 32));
+    const float u = 2.3283064e-10f + (float)c[ii] * 2.3283064e-10f;
+    return u == 1.0f ? 0.0f : u;
+}
+
+// ---------------------------------------------------------------------------------------------
 // CurriculumMasking row arithmetic (ref aecf/AECFLayer.py:130-283), one row of length L in
 // registers.  Shared by the fused gate kernel and the stand-alone mask kernel so both produce
 // bit-identical results for the same (weights, uniforms).

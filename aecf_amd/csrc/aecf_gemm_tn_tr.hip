@@ -86,6 +86,7 @@ __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(Gemm
     const int E = p.E, H = p.H;
     const int EJ = p.Ej > 0 ? p.Ej : p.E;
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    if (POOLED && p.dq.w_k) dqp_rows<BF16>(p.dq, (int)blockIdx.x, (int)gridDim.x);   // side job: dq' for the finalize launch
 
     const unsigned int nK = (unsigned)((E + 127) / 128), nJt = (unsigned)((EJ + 127) / 128);
     unsigned int split_u, tile_u;
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
     const int E = p.E, H = p.H;
     const int EJ = p.Ej > 0 ? p.Ej : p.E;
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    if (p.dq.w_k) dqp_rows<BF16>(p.dq, (int)blockIdx.x, (int)gridDim.x);      // side job: dq' for the finalize launch (aecf_common.h)
 
     const unsigned int nK = (unsigned)((E + 127) / 128), nJt = (unsigned)((EJ + 255) / 256);
     unsigned int split_u, tile_u;

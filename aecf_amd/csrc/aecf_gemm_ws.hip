@@ -121,6 +121,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 
     issue(o_beg, 0);                                              // the first tile flies while the weights load
 
+    // side job of the launch's first block (out-projection of a training-mode forward): the entropy regulariser's final sum
+    // over the statistics kernel's per-block partials (ref aecf/AECFLayer.py:309-314: mean, clamp at 0) -- one wave, fixed order
+    if (MODE == WS_PLAIN && !GATE && p.ent_loss && chunk_u == 0 && group_u == 0 && w == 0) {
+        float acc = 0.f;
+        for (int i = lane; i < p.ent_nblk; i += 64) acc += p.ent_partial[i];
+        acc = reduce_wave(acc);
+        if (lane == 0) reinterpret_cast<unsigned short*>(p.ent_loss)[0] = X::from_f32(fmaxf(acc * p.ent_inv_n, 0.f));
+    }
+
     // ---- resident weights: MFMA A operand, row i = 4 lg' + r of tile c  <->  column ncol0 + 8 (i >> 2) + 4 c + (i & 3)
     //      (so that accumulator lane (lg, r16) holds columns ncol0 + 8 lg + 4 c + 0..3 of row/sample r16)
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w);
@@ -401,6 +410,34 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
 
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     const int E = p.E;
+    // side job, every block of the launch (before any of them leaves): u[h][k] = sum of the u slabs the score-gradient kernel
+    // wrote, elements dealt evenly over the blocks, threads = (element, slab group), groups folded in fixed order through
+    // LDS (the second do buffer: nothing lands there before the first step) -- the finalize launch then reads 16 KB of
+    // reduced u instead of depending on a reduction launch of its own
+    if (p.u_slab_in) {
+        const int n = H_ * E, G = (int)gridDim.x;
+        const int per = (n + G - 1) / G, e0 = (int)blockIdx.x * per;
+        const int ew = (n - e0) < per ? (n - e0) : per;
+        if (ew > 0) {
+            int ewp = 1;
+            while (ewp < ew && ewp < 512) ewp <<= 1;
+            float* scratch = reinterpret_cast<float*>(raw + RAW);
+            for (int base = 0; base < ew; base += ewp) {         // (ew <= 512 whenever the grid has >= n / 512 blocks)
+                const int el = base + (int)(threadIdx.x & (ewp - 1)), sl = (int)threadIdx.x / ewp, nsl = 512 / ewp;
+                float acc = 0.f;
+                if (el < ew)
+                    for (int sb = sl; sb < p.u_nslab; sb += nsl) acc += p.u_slab_in[(int64_t)sb * n + e0 + el];
+                scratch[threadIdx.x] = acc;
+                __syncthreads();
+                if ((int)threadIdx.x < ewp && base + (int)threadIdx.x < ew) {
+                    float t = 0.f;
+                    for (int g = 0; g < nsl; ++g) t += scratch[g * ewp + threadIdx.x];
+                    p.u_out[e0 + base + threadIdx.x] = t;
+                }
+                __syncthreads();
+            }
+        }
+    }
     unsigned int chunk_u, group_u;
     if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(E / BC), chunk_u, group_u)) return;
     const int ncol0 = (int)group_u * BC + CW * w;
@@ -591,9 +628,15 @@ __device__ __forceinline__ float dot2_bf16(unsigned int a, unsigned int b, float
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
 
-template <int KT, int KJ, int HK, int M_, bool PKDOT>
+// WIDE (round 4): the resident weights' rows are permuted so that a lane's accumulators of a tile PAIR hold 8 CONSECUTIVE
+// columns k (k = ncol0 + 32 (ct >> 1) + 8 lg + 4 (ct & 1) + reg, the trick of the plain kernel's 16-byte stores), so the dot
+// reads x in 16-byte pieces: half the LDS reads of the 8-byte form -- each of them is waited for right in front of its use
+// (the kernel has no registers left to run them ahead: profiles/r01_pmc_notes.md, end of round 3).
+template <int KT, int KJ, int HK, int M_, bool PKDOT, int VAR>
 __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __restrict__ u_slab, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
+    constexpr bool WIDE = VAR >= 1;                               // 16-byte dot reads (VAR 0: the 8-byte form of rounds 2-3)
+    constexpr bool NOBR = VAR >= 2;                               // partial dots leave the wave without a branch (below)
     constexpr int E = 32 * KT, JB = 32 * KJ, NCT = KT / 4;        // a wave owns E / 8 = 16 NCT columns k
     constexpr int HBL = KJ / HK;                                  // heads per block
     constexpr int ROWX = 2 * E, ROWD = 2 * JB;
@@ -639,9 +682,11 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     // ---- resident weights: A operand row r16 of column tile ct <-> k = ncol0 + 16 ct + r16, K = j
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.wvt);
     u32x4 wreg[KJ][NCT];
+    static_assert(!WIDE || NCT % 2 == 0, "tile pairs");
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        const unsigned short* wr = wsrc + (int64_t)(ncol0 + 16 * ct + r16) * E + jbase + 8 * lg;
+        const int krow = WIDE ? ncol0 + 32 * (ct >> 1) + 8 * (r16 >> 2) + 4 * (ct & 1) + (r16 & 3) : ncol0 + 16 * ct + r16;
+        const unsigned short* wr = wsrc + (int64_t)krow * E + jbase + 8 * lg;
 #pragma unroll
         for (int ks = 0; ks < KJ; ++ks) wreg[ks][ct] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
     }
@@ -651,7 +696,11 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     // the 8-byte piece of x row (r16, m = 0) that holds columns ncol0 + 4 lg .. + 3 of column tile 0; tile ct adds
     // 2 ct to the chunk index BEFORE the xor with the sample, which (2 ct < 8, ncol0 / 8 a multiple of 8) is an xor of the
     // byte offset with 32 ct
-    const int xaddr0 = r16 * M_ * ROWX + (((((ncol0 >> 3) + (lg >> 1))) ^ r16) << 4) + 8 * (lg & 1);
+    // WIDE: the 16-byte piece that holds columns ncol0 + 8 lg .. + 7 of tile pair 0; pair c2 adds 4 to the chunk index (bit 2 of
+    // (ncol0 >> 3) + lg is clear), an xor of the byte offset with 64.  ds_read_b128's 16-lane groups then touch 16 different
+    // 16-byte slots of the 256-byte bank window (lane-group rows {0-3,12-15 | 4-11} xor two chunk numbers one apart): conflict-free.
+    const int xaddr0 = WIDE ? r16 * M_ * ROWX + ((((ncol0 >> 3) + lg) ^ r16) << 4)
+                            : r16 * M_ * ROWX + (((((ncol0 >> 3) + (lg >> 1))) ^ r16) << 4) + 8 * (lg & 1);
     // transposed-read addresses of the u product (constant over the steps).  The K index of that product is any
     // numbering of the tile's (sample, modality) rows, as long as the ds operand arrays use the same one -- and the
     // row stride is a multiple of the 256-byte bank window, so rows read together must differ in their swizzle key
@@ -728,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
         constexpr int HG = (HBL % 2 == 0 && !PKDOT) ? 2 : 1;
         int xa[NCT];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) xa[ct] = cur * XT + (xaddr0 ^ (32 * ct));
+        for (int ct = 0; ct < NCT; ++ct) xa[ct] = cur * XT + (WIDE ? (xaddr0 ^ (64 * (ct >> 1))) : (xaddr0 ^ (32 * ct)));
         float* pw = part + w * PSTR + r16;
 #pragma unroll
         for (int h0 = 0; h0 < HBL; h0 += HG) {
@@ -760,6 +809,22 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 float a[HG];
 #pragma unroll
                 for (int g = 0; g < HG; ++g) a[g] = 0.f;
+                if (WIDE) {
+#pragma unroll
+                    for (int c2 = 0; c2 < NCT / 2; ++c2) {
+                        const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + xa[2 * c2] + m * ROWX);
+                        float xf[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            xf[2 * i] = __uint_as_float(xv[i] << 16);
+                            xf[2 * i + 1] = __uint_as_float(xv[i] & 0xffff0000u);
+                        }
+#pragma unroll
+                        for (int g = 0; g < HG; ++g)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) a[g] = fmaf(P[g][2 * c2 + (i >> 2)][i & 3], xf[i], a[g]);
+                    }
+                } else
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     const u32x2 xv = *reinterpret_cast<const u32x2*>(xb + xa[ct] + m * ROWX);
@@ -781,6 +846,18 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                         }
                     }
                 }
+                if (NOBR) {
+                    // the same sums as a reduce-scatter: one row swap pairs the group's two heads (even rows end with head g = 0,
+                    // odd rows with g = 1, each summed over a row pair), one half swap adds the halves; every lane then holds
+                    // the total of head h0 + (lg & 1) and stores it -- lanes 32 apart store the same value to the same word.
+                    // No exec-mask branch per value (12 per step before): the step's dot phase is ONE basic block, so the
+                    // next modality's x reads can be scheduled above this one's arithmetic.
+                    const unsigned int u0 = __float_as_uint(a[0]), u1 = __float_as_uint(a[HG - 1]);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(u0, u1, false, false);
+                    const unsigned int us = __float_as_uint(__uint_as_float(r1[0]) + __uint_as_float(r1[1]));
+                    const auto r2 = __builtin_amdgcn_permlane32_swap(us, us, false, false);
+                    pw[((h0 + (HG == 2 ? (lg & 1) : 0)) * M_ + m) * 16] = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+                } else
 #pragma unroll
                 for (int g = 0; g < HG; ++g) {
                     // sum over the wave's four lane groups (lanes r16, r16 + 16, + 32, + 48): rows swapped pairwise, then halves
@@ -865,10 +942,18 @@ int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     rpb = (rpb + 15) / 16 * 16;
     const int64_t nchunk = (a.B + rpb - 1) / rpb;
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
-    auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
-    return (int)nchunk;
+    const int var = (KT / 4) % 2 == 0 ? env_dsu_var() : 0;        // (A/B: AECF_DEBUG=dsu_var=0|1|2)
+#define DSU_GO(V_)                                                                                                             \
+    {                                                                                                                          \
+        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false, V_>;                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);                                                      \
+        return (int)nchunk;                                                                                                    \
+    }
+    if (var == 0) DSU_GO(0)
+    if (var == 1) DSU_GO(1)
+    DSU_GO(2)
+#undef DSU_GO
 }
 
 template <int KT, int HK, int M_>

@@ -51,10 +51,12 @@ struct GateArgs {
     void* i_target = nullptr; // [B] activation dtype filled with target_value (info['target_entropy']) or null
     float target_value = 0.f;
     float* ent_partial = nullptr;   // [(B + 255) / 256] sums of (nan_to_num(H) - target_value)^2 per 256 rows, or null (gate_stats only)
+    PhiloxDraw ph;                  // mask_mode 1 without a uniforms tensor: the kernel draws them itself (aecf_common.h)
     int64_t B;
     int M, E, H;
     MaskCfg mask;
 };
+void launch_philox_uniforms(int64_t n, const PhiloxDraw& ph, float* out, hipStream_t s);   // out[i] = philox_uniform_at(ph, i)
 void launch_gate_fwd(int dtype, const GateArgs& a, hipStream_t s);
 void launch_gate_stats(int dtype, const GateArgs& a, hipStream_t s);   // head mean + masking from probs (scores fused elsewhere)
 
@@ -80,6 +82,13 @@ struct GemmNtArgs {
     const void* g_ahi = nullptr;      // [HPAD,K] dtype
     const void* g_alo = nullptr;      // [HPAD,K] dtype
     const uint8_t* g_kpm = nullptr;   // [R,M] or null
+    // plain product only, optional side job of the launch's first block (weight-stationary kernel): the entropy regulariser's
+    // final sum -- loss = max(sum(ent_partial[0 .. ent_nblk)) * ent_inv_n, 0) in the activation dtype (ref :309-314) -- so that
+    // the forward needs no launch of its own for it (the partials come from the statistics kernel that ran before)
+    const float* ent_partial = nullptr;
+    int ent_nblk = 0;
+    float ent_inv_n = 0.f;
+    void* ent_loss = nullptr;         // [1] dtype
 };
 void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
 void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s);   // pooled == 1 path
@@ -111,6 +120,11 @@ struct BwdGArgs {
     float log_M;
     const void* wvt_frag = nullptr;  // optional fragment-major copy of W_v^T (FragJobs): faster dx weight prologue
     int cu_budget = 0;               // dx_ws2: blocks to launch at most (0 = one per CU, 256); fewer leaves CUs to a collective
+    // dx_ws2 side job (optional): u_out[H, E] = sum over the u_nslab slabs [H, E] the score-gradient kernel wrote before this
+    // launch -- spread over the launch's blocks, done while their weights load -- so that the finalize launch finds u reduced
+    const float* u_slab_in = nullptr;
+    float* u_out = nullptr;
+    int u_nslab = 0;
 };
 void launch_bwd_g(int dtype, const BwdGArgs& a, bool dx, hipStream_t s);
 // score gradient from the saved value projections: da[b,h,m] = do_h[b] . V_h[b,m]  (memory-bound, one wave per sample)
@@ -144,6 +158,7 @@ struct GemmTnArgs {
     int64_t u_rows_per_split;
     int pooled;
     int parts = 0;            // pooled: 0 = main product + u, 1 = main product only, 2 = u only (separate stage timing)
+    DqpJob dq;                // bf16 transposed-read kernels only: side job of the launch (aecf_common.h); w_k == null: off
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b64_tr_b16 form (main product only)
@@ -161,6 +176,7 @@ struct ReduceSegs {
 bool env_no_ws();
 bool env_no_wide_tn();
 bool env_no_slab();
+int env_dsu_var();
 
 void launch_reduce_segments(const ReduceSegs& r, hipStream_t s);
 
@@ -171,8 +187,8 @@ struct FinalizeArgs {
     const void* query;
     const float* qs;
     const float* u;       // [HPAD,E] reduced
-    float* dqp;           // [E] scratch
-    float* dq_part;       // [E/64, E] scratch (dquery partials per j-block)
+    const float* dqp;     // [E] dq' (DqpJob: side job of the dW_v launch, or launch_dqp)
+    float* dq_part;       // (unused since round 4)
     void* dw_in;          // [3E,E]  float32, or bf16 when grad_bf16
     void* db_in;          // [3E]
     void* dquery;         // [E]
@@ -180,7 +196,8 @@ struct FinalizeArgs {
     float scale;
     int grad_bf16;
 };
-void launch_finalize(int dtype, const FinalizeArgs& a, hipStream_t s);
+void launch_dqp(int dtype, const DqpJob& q, hipStream_t s);        // dq' as its own small launch (shapes without the side job)
+void launch_finalize_all(int dtype, const FinalizeArgs& a, const ReduceSegs& r, hipStream_t s);   // slab reduction + the above, ONE launch
 
 // ---------------- stand-alone pieces ----------------
 void launch_mask_fwd(int64_t rows, int L, const MaskCfg& cfg, const float* w, const float* u, float* masked,

@@ -438,6 +438,16 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const unsigned short
     }
 }
 
+// the in-kernel uniform draw on its own (aecf_philox_uniforms: tests against torch.rand, callers that want the tensor)
+__global__ __launch_bounds__(256) void philox_uniforms_kernel(int64_t n, PhiloxDraw ph, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = philox_uniform_at(ph, i);
+}
+
+void launch_philox_uniforms(int64_t n, const PhiloxDraw& ph, float* out, hipStream_t s) {
+    philox_uniforms_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(n, ph, out);
+}
+
 void launch_cast_bf16_f32(const void* src, float* dst, int64_t n, hipStream_t s) {
     if (n <= 0 || !src) return;
     cast_bf16_f32_kernel<<<dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s>>>((const unsigned short*)src, dst, n);

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(GateArgs p) {
 #pragma unroll
                 for (int m = 0; m < M_; ++m) {
                     w[m] = wsel[m];
-                    u[m] = (p.mask.mode == 1 && p.uniforms) ? p.uniforms[bs * M_ + m] : 0.f;
+                    u[m] = p.mask.mode != 1 ? 0.f : (p.uniforms ? p.uniforms[bs * M_ + m] : (p.ph.threads ? philox_uniform_at(p.ph, bs * M_ + m) : 0.f));
                 }
                 float ent, rate;
                 unsigned int bits;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(GateArgs p) {
 #pragma unroll
             for (int m = 0; m < M_; ++m) {
                 w[m] = wsel[m];
-                u[m] = (p.mask.mode == 1 && p.uniforms) ? p.uniforms[bs * M_ + m] : 0.f;
+                u[m] = p.mask.mode != 1 ? 0.f : (p.uniforms ? p.uniforms[bs * M_ + m] : (p.ph.threads ? philox_uniform_at(p.ph, bs * M_ + m) : 0.f));
             }
             float ent, rate;
             unsigned int bits;

@@ -62,6 +62,7 @@ struct RowFwdArgs {
     const unsigned short* a_lo;
     const uint8_t* kpm;             // [B,M] or null
     const float* uniforms;          // [B,M] or null
+    PhiloxDraw ph;                  // drawn in the kernel when uniforms is null (aecf_common.h)
     unsigned short* y;              // [B,E]
     unsigned short* o;              // [B,E] saved heads or null
     unsigned short* v;              // [B,M,E] saved value projections or null
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void row_fwd_kernel(RowFwdArgs p, int ntile
 #pragma unroll
                     for (int m = 0; m < M_; ++m) {
                         wv[m] = wsel[m];
-                        u[m] = (p.mask.mode == 1 && p.uniforms) ? p.uniforms[bs * M_ + m] : 0.f;
+                        u[m] = p.mask.mode != 1 ? 0.f : (p.uniforms ? p.uniforms[bs * M_ + m] : (p.ph.threads ? philox_uniform_at(p.ph, bs * M_ + m) : 0.f));
                     }
                     float ent, rate;
                     unsigned int bits;
@@ -411,7 +412,7 @@ void launch_row_fwd(const GateArgs& g, const GemmNtArgs& v, const GemmNtArgs& y,
     RowFwdArgs a;
     a.x = (const unsigned short*)g.x; a.w_v = (const unsigned short*)v.w; a.b_v = (const unsigned short*)v.bias;
     a.w_o = (const unsigned short*)y.w; a.b_o = (const unsigned short*)y.bias;
-    a.a_hi = (const unsigned short*)g.a_hi; a.a_lo = (const unsigned short*)g.a_lo; a.kpm = g.kpm; a.uniforms = g.uniforms;
+    a.a_hi = (const unsigned short*)g.a_hi; a.a_lo = (const unsigned short*)g.a_lo; a.kpm = g.kpm; a.uniforms = g.uniforms; a.ph = g.ph;
     a.y = (unsigned short*)y.c; a.o = (unsigned short*)v.c; a.v = (unsigned short*)v.v_out; a.probs = g.probs;
     a.attn_w = g.attn_w; a.masked_w = g.masked_w; a.entropy = g.entropy; a.mask_rate = g.mask_rate;
     a.i_attn_w = (unsigned short*)g.i_attn_w; a.i_masked_w = (unsigned short*)g.i_masked_w;

@@ -130,6 +130,7 @@ def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=Non
     _, world = world_info(group)
     if world == 1:
         return
+    keep_f32_grad_sums(True)                 # (a data-parallel run: bf16 gradients are rounded once, after the collective)
     by_dtype = {}
     for p in params:
         by_dtype.setdefault(p.dtype, []).append(p)
@@ -141,6 +142,18 @@ def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=Non
             for p in ps:
                 p.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
+
+
+def keep_f32_grad_sums(on: bool = True) -> None:
+    """Reduced-precision parameters (bf16): have the fused backward keep its float32 batch sums next to the bf16 gradients it
+    hands autograd, so that ``all_reduce_grads`` / ``GradOverlap`` move and average the float32 values and round the MEAN once
+    into ``p.grad`` -- an N-rank gradient then differs from the one-rank gradient by float32 summation order only, not by a
+    bf16 rounding per rank (up to one bf16 ulp, 7.8e-3 of an element).  Costs one cast kernel per backward.  Turned on by
+    ``broadcast_parameters`` when world > 1."""
+    from . import layer
+    layer._keep_f32_sums = bool(on)
+    if not on:
+        layer._f32_sums.clear()
 
 
 def shard_loss_scale(b_local: int, b_global: int, world: int) -> float:
@@ -192,10 +205,13 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
     if fp32 is None:
         fp32 = reduced
     if fp32 and reduced:
-        wide = flat.float() if flat is not None else torch.cat([p.grad.reshape(-1).float() for p in params])
-        dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
+        from . import layer
+        wide = layer.take_f32_sums(flat)              # the backward's own float32 sums, where it left them (keep_f32_grad_sums)
+        if wide is None:
+            wide = flat.float() if flat is not None else torch.cat([p.grad.reshape(-1).float() for p in params])
         if average:
-            wide.div_(world)
+            wide.div_(world)                          # (before the sum, as GradOverlap does: the two paths stay bit-equal)
+        dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
         if flat is not None:
             flat.copy_(wide)                          # one rounding, in place over the allocation autograd holds
             return
@@ -274,18 +290,31 @@ class GradOverlap:
             flat.div_(world)
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
-    def __call__(self, flat: torch.Tensor, event) -> None:
+    def __call__(self, flat: torch.Tensor, event, flat32: Optional[torch.Tensor] = None) -> None:
+        # reduced-precision gradients whose float32 sums the backward kept: the collective runs on THOSE and finish() rounds the
+        # mean into `flat` (the allocation autograd holds) once
+        low = None
+        if flat32 is not None:
+            from . import layer
+            layer._f32_sums.pop(flat.untyped_storage().data_ptr(), None)     # consumed here, not by all_reduce_grads
+            low, flat = flat, flat32
         if self.pending:
             # A SECOND fused backward inside one region (two pool applications, or two backward() calls): autograd is about
             # to ADD this call's gradients into the p.grad the first call left -- on the main stream, reading both allocations.
             # Nothing may mutate them behind its back: the first collective is waited for here and this one runs on the main
             # stream (no overlap for it); the sum autograd forms is then the sum of two reduced gradients.
-            for _, work in self.pending:
+            for low_, work, wide_ in self.pending:
                 if work is not None:
                     work.wait()
+                if wide_ is not None:                        # the first collective's float32 mean -> the allocation autograd adds into
+                    torch.cuda.current_stream().wait_stream(self.stream)
+                    low_.copy_(wide_)
+            self.pending = [(a_, None, None) for a_, _, _ in self.pending]
             torch.cuda.current_stream().wait_stream(self.stream)
             self._reduce(flat, async_op=False)
-            self.pending.append((flat, None))
+            if low is not None:
+                low.copy_(flat)
+            self.pending.append((flat if low is None else low, None, None))
             return
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=flat.device)
@@ -293,7 +322,7 @@ class GradOverlap:
         with torch.cuda.stream(self.stream):
             work = self._reduce(flat, async_op=True)
         flat.record_stream(self.stream)
-        self.pending.append((flat, work))
+        self.pending.append((flat if low is None else low, work, None if low is None else flat))
 
     def finish(self, params: Iterable[torch.nn.Parameter]) -> None:
         """Wait for the collectives issued behind dx; all-reduce whatever they did not cover."""
@@ -306,11 +335,14 @@ class GradOverlap:
             all_reduce_grads(params, self.group, self.average)
             return
         spans = []
-        for flat, work in pending:
+        for flat, work, wide in pending:
             if work is not None:
                 work.wait()
             spans.append((flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
         torch.cuda.current_stream().wait_stream(self.stream)
+        for flat, _, wide in pending:
+            if wide is not None:
+                flat.copy_(wide)                             # ONE rounding of the float32 mean, in place
         rest = [p for p in params if not any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]
         if rest:
             all_reduce_grads(rest, self.group, self.average)

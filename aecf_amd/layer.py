@@ -58,6 +58,46 @@ def _draw_uniforms(shape, device, uniforms: Optional[torch.Tensor] = None,
     return torch.rand(shape, dtype=torch.float32, device=device, generator=generator)
 
 
+def _philox_draw(n: int, device: torch.device, generator: Optional[torch.Generator] = None):
+    """The generator call ``torch.rand(n, device=device, generator=generator)`` WITHOUT making it: returns
+    ``(seed, offset, threads)`` -- the generator's state before the call and the thread count of torch's launch
+    (ATen/native/cuda/DistributionTemplates.h: blocks of 256, grid = min(ceil(n / 256), CUs * max_threads_per_CU / 256)) --
+    and advances the generator by what that call consumes (4 per 4 * threads elements, one iteration here).  The statistics
+    kernel evaluates the same Philox4x32-10 stream element by element (AECF_DRAW_UNIFORMS, include/aecf_hip.h), so the masks are
+    those of the tensor path bit for bit (``tests/test_pool_gpu.py::test_in_kernel_uniforms_equal_torch_rand``).
+    Returns None where the offset cannot be read on the host: while the stream is being captured into a graph (a replay
+    must see a fresh offset: torch's graph-safe generator state does that for ``torch.rand``) or for a non-device generator."""
+    if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return None
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    gen = generator if generator is not None else torch.cuda.default_generators[index]
+    if gen.device.type != "cuda":
+        return None
+    props = _device_props(index)
+    blocks = min((n + 255) // 256, props[0] * (props[1] // 256))
+    threads = 256 * blocks
+    increment = ((n - 1) // (threads * 4) + 1) * 4
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(offset + increment)
+    return int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset), int(threads)
+
+
+_props_cache: Dict[int, Tuple[int, int]] = {}
+
+
+def _device_props(index: int) -> Tuple[int, int]:
+    p = _props_cache.get(index)
+    if p is None:
+        dp_ = torch.cuda.get_device_properties(index)
+        p = (int(dp_.multi_processor_count), int(dp_.max_threads_per_multi_processor))
+        _props_cache[index] = p
+    return p
+
+
+# in-kernel draw of the curriculum mask's uniforms (no torch.rand launch, no [B,M] tensor); tests switch it off to compare
+_DRAW_IN_KERNEL = True
+
+
 def _require_device(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(
@@ -75,6 +115,29 @@ _SHARE_PREP = True
 # gradient last and to announce (a HIP event) the moment the five parameter gradients are final, and hands the hook that
 # event together with the allocation that holds them, so that their all-reduce runs behind the dx kernel.  None = off.
 _param_grads_hook = None
+
+# Data parallel with reduced-precision parameters (bf16): the backward's float32 batch sums are rounded ONCE, after the
+# collective, instead of once per rank before it and once more after (which puts a two-rank gradient up to a bf16 ulp, 7.8e-3
+# of the element, away from the one-rank gradient).  With the switch on (dp.broadcast_parameters turns it on when world > 1;
+# dp.keep_f32_grad_sums) the backward asks the library for float32 gradients, hands autograd their bf16 rounding as usual and
+# leaves the float32 run here, keyed by the bf16 allocation, for dp.all_reduce_grads / dp.GradOverlap to reduce and round.
+_keep_f32_sums = False
+_f32_sums: Dict[int, Tuple[torch.Tensor, torch.Tensor, int]] = {}     # bf16 storage pointer -> (flat, flat32, flat._version)
+
+
+def take_f32_sums(flat: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The float32 sums behind the reduced-precision gradient run ``flat`` (as dp.flat_grad_alias returns it), if the last
+    fused backward left them and nothing has written to that run since; consumed by the call."""
+    if flat is None or not _f32_sums:
+        return None
+    hit = _f32_sums.pop(flat.untyped_storage().data_ptr(), None)
+    if hit is None:
+        return None
+    mine, wide, version = hit
+    if (mine._version != version or mine.data_ptr() != flat.data_ptr() or mine.numel() != flat.numel()
+            or mine.dtype != flat.dtype):
+        return None
+    return wide
 
 # what the library answers per call shape (status of aecf_pool_check, workspace sizes, whether the backward wants V):
 # pure functions of the description, asked once per shape instead of on every call (each ctypes round trip is ~1-2 us of a
@@ -102,7 +165,7 @@ class _PoolFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, q, w_in, b_in, w_out, b_out, kpm, uniforms, num_heads, mask_mode, min_active,
-                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None, casts=None, side=None):
+                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None, casts=None, side=None, philox=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)       # unused outputs arrive as None, not as zero tensors (fill + cast launches)
         B, M, E = x.shape
@@ -149,10 +212,18 @@ class _PoolFunction(torch.autograd.Function):
         i_target = torch.empty(B, dtype=dt, device=dev) if (mask_mode == 1 and target_value is not None) else None
         # partial sums of the entropy regulariser over this call's rows, left behind by the kernel that writes the entropies
         # (training mode): CurriculumMasking.entropy_loss(info['entropy']) is then one small launch (side = a dict of the caller)
-        ent_partial = None
+        # ... and, ABI v8, the loss itself: the out-projection launch's first block adds the partials up (no launch at all)
+        ent_partial = ent_loss = None
         if side is not None and mask_mode == 1 and target_value is not None:
             ent_partial = torch.empty((B + 255) // 256, dtype=torch.float32, device=dev)
-            side["ent_partial"] = (ent_partial, B, float(target_value))
+            if not f32_info:
+                ent_loss = torch.empty(1, dtype=dt, device=dev)
+            side["ent_partial"] = (ent_partial, B, float(target_value), ent_loss)
+        flags = 0
+        ph_seed = ph_off = ph_threads = 0
+        if philox is not None and mask_mode == 1 and uniforms is None:
+            ph_seed, ph_off, ph_threads = philox
+            flags |= _lib.AECF_DRAW_UNIFORMS
         ws_bytes = fwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         args = _lib.PoolFwdArgs(
@@ -161,7 +232,8 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(ws), ws_bytes,
             None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd),
             _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate), _ptr(saved_prep),
-            _ptr(i_target), 0.0 if target_value is None else float(target_value), 0, _ptr(ent_partial))
+            _ptr(i_target), 0.0 if target_value is None else float(target_value), flags, _ptr(ent_partial),
+            ph_seed, ph_off, ph_threads, _ptr(ent_loss))
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
         ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep)
         ctx.desc = desc
@@ -200,7 +272,9 @@ class _PoolFunction(torch.autograd.Function):
         gdt = dt if all(p is None or p == dt for p in ctx.param_dtypes) else torch.float32
         # one allocation for the five of them: autograd keeps these tensors as p.grad without copying, so a data-parallel
         # caller can all-reduce the whole run in place with a single collective (aecf_amd/dp.py: all_reduce_grads)
-        flat = torch.empty(4 * E * E + 5 * E, dtype=gdt, device=dev)
+        keep32 = _keep_f32_sums and gdt != torch.float32
+        out_dt = torch.float32 if keep32 else gdt                 # what the library writes
+        flat = torch.empty(4 * E * E + 5 * E, dtype=out_dt, device=dev)
         dquery, dw_in, db_in, dw_out, db_out = flat.split([E, 3 * E * E, 3 * E, E * E, E])
         dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
         ws_bytes = ctx.bwd_ws_bytes
@@ -216,10 +290,21 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
             _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes,
             None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd),
-            _DTYPES[gdt], 0, _ptr(saved_prep), None if early is None else early.cuda_event)
+            _DTYPES[out_dt], 0, _ptr(saved_prep), None if early is None else early.cuda_event)
         _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")
+        flat32 = None
+        if keep32:
+            # autograd gets this rank's sums rounded to the parameters' dtype (what it would have got anyway); the float32 run
+            # stays behind for the collective, which rounds the MEAN once into the same allocation
+            flat32 = flat
+            flat = flat32.to(gdt)
+            dquery, dw_in, db_in, dw_out, db_out = flat.split([E, 3 * E * E, 3 * E, E * E, E])
+            dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
+            if len(_f32_sums) > 8:
+                _f32_sums.clear()
+            _f32_sums[flat.untyped_storage().data_ptr()] = (flat, flat32, flat._version)
         if hook is not None:
-            hook(flat, early)                      # [dquery | dw_in | db_in | dw_out | db_out]: final once `early` has fired
+            hook(flat, early, flat32)              # [dquery | dw_in | db_in | dw_out | db_out]: final once `early` has fired
         needs = ctx.needs_input_grad
         return (dx if needs[0] else None,
                 dquery.to(qd).reshape(ctx.q_shape) if needs[1] else None,
@@ -227,7 +312,7 @@ class _PoolFunction(torch.autograd.Function):
                 db_in.to(bid) if (ctx.has_bias[0] and needs[3]) else None,
                 dw_out.to(wod) if needs[4] else None,
                 db_out.to(bod) if (ctx.has_bias[1] and needs[5]) else None,
-                None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def precise_forward_backward(x: torch.Tensor, query: torch.Tensor, w_in: torch.Tensor, b_in: Optional[torch.Tensor],
@@ -510,12 +595,14 @@ class CurriculumMasking(nn.Module):
         if tag is not None and not entropy.requires_grad and entropy.dtype in _DTYPES:
             # info['entropy'] of a fused pool forward, untouched: the kernel that wrote it left the per-block sums of
             # (nan_to_num(H) - target)^2 behind (aecf_pool_fwd_args.ent_loss_partial) -- one small launch adds them up
-            (partial, n, target), version = tag
+            (partial, n, target, ready), version = tag
             want = math.log(float(seq_len)) * self.entropy_target if seq_len > 1 else 0.0
             # ... and UNTOUCHED is checked, not assumed: an in-place edit of the tensor (info['entropy'].clamp_(...), .mul_())
             # or of any view of it moves the version counter they share, and the partial sums no longer describe the values:
             # the full kernel below reads the tensor as it is now
             if entropy._version == version and entropy.numel() == n and abs(want - target) <= 1e-6 * max(1.0, abs(want)):
+                if ready is not None and ready.dtype == entropy.dtype:
+                    return ready.reshape(())       # the forward's out-projection launch already added the partials up
                 loss = torch.empty(1, dtype=entropy.dtype, device=entropy.device)
                 _lib.check(_lib.load().aecf_entropy_loss_from_partials(n, _DTYPES[entropy.dtype], _ptr(partial), _ptr(loss),
                                                                        _stream()), "aecf_entropy_loss_from_partials")
@@ -739,14 +826,18 @@ class MultimodalAttentionPool(nn.Module):
 
         cm = self.curriculum_masking
         mask_mode = 0
-        mask_u = None
+        mask_u = philox = None
         if cm is not None:
             mask_mode = 1 if cm.training else 2
             if mask_mode == 1 and src_len <= 1:
                 mask_mode = 0          # ref :160-167 early-out: handled on the host below
             if mask_mode == 1:
-                # one float32 uniform per weight element, row-major, default generator (ref :204)
-                mask_u = _draw_uniforms((batch_size, tgt_len, src_len), x.device, uniforms, generator)
+                # one float32 uniform per weight element, row-major, default generator (ref :204): drawn by the statistics
+                # kernel itself from the generator's (seed, offset) where that can be read on the host, else as a tensor
+                if uniforms is None and _DRAW_IN_KERNEL:
+                    philox = _philox_draw(batch_size * tgt_len * src_len, x.device, generator)
+                if philox is None:
+                    mask_u = _draw_uniforms((batch_size, tgt_len, src_len), x.device, uniforms, generator)
         a = self.attention
         tgt_value = math.log(float(src_len)) * cm.entropy_target if mask_mode == 1 else None        # ref :273
         side: Dict[str, Any] = {}
@@ -754,7 +845,8 @@ class MultimodalAttentionPool(nn.Module):
             x, q_base, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, kpm, mask_u,
             self.num_heads, mask_mode, 1 if cm is None else int(cm.min_active),
             0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8,
-            False, tgt_value, self._activation_dtype_params(x.dtype) if a.in_proj_weight.dtype != x.dtype else None, side)
+            False, tgt_value, self._activation_dtype_params(x.dtype) if a.in_proj_weight.dtype != x.dtype else None, side,
+            philox)
 
         dt = x.dtype
         attn_output = y.unsqueeze(1) if self.batch_first else y.unsqueeze(0)          # [B,1,E] / [1,B,E]

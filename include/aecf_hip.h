@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AECF_ABI_VERSION 7
+#define AECF_ABI_VERSION 8
 
 typedef enum aecf_status {
     AECF_OK = 0,
@@ -123,9 +123,24 @@ typedef struct aecf_pool_fwd_args {
      * entropies, so that a later entropy_loss of exactly this tensor is ONE small launch (aecf_entropy_loss_from_partials)
      * instead of a pass over the rows.  NULL = not wanted. */
     float* ent_loss_partial;
+    /* ABI v8.  AECF_DRAW_UNIFORMS (mask_mode 1, uniforms == NULL): the statistics kernel draws the Bernoulli uniforms of ref
+     * aecf/AECFLayer.py:204 itself -- for weight element i exactly the value `torch.rand(B*M, device=...)` would hold at i when
+     * the device generator stands at (philox_seed, philox_offset): Philox4x32-10, subsequence = the element's thread of
+     * torch's launch of philox_threads threads (its grid: min(ceil(n / 256), CUs * 8) blocks of 256), 2^-32 + v 2^-32 with 1.0
+     * mapped to 0.0.  The caller advances its generator by what that torch call would have consumed (4 per 4*threads elements).
+     * One launch and a [B,M] float32 tensor less per step; a caller who needs a recorded draw (parity tests, data-parallel
+     * shards of one global draw) keeps passing `uniforms`. */
+    uint64_t philox_seed;
+    uint64_t philox_offset;
+    uint32_t philox_threads;
+    /* ABI v8, optional (mask_mode 1, with ent_loss_partial): [1] dtype, CurriculumMasking.entropy_loss over the rows of this
+     * call -- max(mean((nan_to_num(H) - target)^2), 0), ref :285-314 -- written by the out-projection launch's first block from
+     * the partial sums (no launch of its own; shapes the weight-stationary kernel does not take: one small launch).  NULL = off. */
+    void* ent_loss;
 } aecf_pool_fwd_args;
 
 #define AECF_PRECISE 1
+#define AECF_DRAW_UNIFORMS 2
 
 /* Backward (autograd transpose of the above). */
 typedef struct aecf_pool_bwd_args {
@@ -184,6 +199,12 @@ int aecf_pool_wants_saved_v(const aecf_pool_desc* d);
 size_t aecf_pool_precise_workspace_bytes(const aecf_pool_desc* d, int backward);
 /* bytes of the optional parameter-preparation buffer shared by forward and backward (saved_prep) */
 size_t aecf_pool_prep_bytes(const aecf_pool_desc* d);
+
+/* The generator call of AECF_DRAW_UNIFORMS on its own (tests, callers that want the tensor): out[i], i < n, = the float32
+ * uniform described at aecf_pool_fwd_args.philox_seed.  aecf_philox_host evaluates one element on the host (known-answer
+ * tests; `raw` != NULL additionally receives the four 32-bit outputs of the Philox4x32-10 block the element comes from). */
+int aecf_philox_uniforms(int64_t n, uint64_t seed, uint64_t offset, uint32_t threads, float* out, void* stream);
+float aecf_philox_host(uint64_t seed, uint64_t offset, uint32_t threads, int64_t element, uint32_t* raw);
 
 int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream);
 int aecf_pool_backward(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, void* stream);

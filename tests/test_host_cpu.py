@@ -37,7 +37,8 @@ def test_header_symbols_are_exported(built_library):
 def test_struct_layout_matches_header():
     # include/aecf_hip.h: aecf_pool_desc = int64 + 6*int32 + 3*float = 44 -> padded to 48
     assert ctypes.sizeof(_lib.PoolDesc) == 48
-    assert ctypes.sizeof(_lib.PoolFwdArgs) == 27 * 8
+    assert ctypes.sizeof(_lib.PoolFwdArgs) == 31 * 8          # ABI v8: + philox_seed, philox_offset, philox_threads (+ pad), ent_loss
+    assert _lib.PoolFwdArgs.philox_seed.offset == 216 and _lib.PoolFwdArgs.ent_loss.offset == 240
     assert ctypes.sizeof(_lib.PoolBwdArgs) == 24 * 8
 
 
@@ -199,3 +200,42 @@ def test_cast_cache_follows_data_writes():
         pool.attention.in_proj_weight.data.mul_(2.0)                           # invisible to the version counter ...
         pool.invalidate_cast_cache()                                           # ... hence the explicit call
         assert torch.equal(pool._activation_dtype_params(torch.bfloat16)[0].float(), c0.float())
+
+
+def _philox_py(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), restated."""
+    c, k = list(ctr), list(key)
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+    return c
+
+
+def test_philox_known_answers_and_element_mapping(built_library):
+    """The generator behind AECF_DRAW_UNIFORMS (include/aecf_hip.h): Philox4x32-10 against the Random123 known-answer
+    vectors, and the library's host evaluation of 'the uniform torch.rand puts at element i' against the restatement of
+    torch's launch geometry (thread = i mod T in iteration i // 4T, component (i mod 4T) // T; counter = offset / 4 +
+    iteration; 2^-32 + v 2^-32, 1.0 -> 0.0)."""
+    import numpy as np
+    assert _philox_py([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert _philox_py([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert _philox_py([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    lib = built_library
+    raw = (ctypes.c_uint32 * 4)()
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        seed = int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2))
+        offset = int(rng.integers(0, 2 ** 40)) * 4
+        threads = 256 * int(rng.integers(1, 2049))
+        element = int(rng.integers(0, 2 ** 33))
+        got = lib.aecf_philox_host(seed, offset, threads, element, raw)
+        it, rem = divmod(element, 4 * threads)
+        ii, idx = divmod(rem, threads)
+        ctr = offset // 4 + it
+        want_raw = _philox_py([ctr & 0xFFFFFFFF, ctr >> 32, idx & 0xFFFFFFFF, idx >> 32], [seed & 0xFFFFFFFF, seed >> 32])
+        assert list(raw) == want_raw
+        u = np.float32(2.3283064e-10) + np.float32(want_raw[ii]) * np.float32(2.3283064e-10)
+        u = np.float32(0.0) if u == np.float32(1.0) else u
+        assert np.float32(got) == u and 0.0 <= got < 1.0

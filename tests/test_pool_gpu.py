@@ -744,6 +744,68 @@ def test_entropy_loss_from_the_forward_partial_sums(dtype, B, M, E, H):
     assert abs(float(other) - float(plain)) > 1e-4
 
 
+@pytest.mark.parametrize("n", [1, 255, 4097, 196608, 524288 + 77, 2100000])
+def test_in_kernel_uniforms_equal_torch_rand(n):
+    """AECF_DRAW_UNIFORMS (ABI v8): the generator call the statistics kernel makes per weight element is the one torch.rand
+    makes for that element -- same values bit for bit from the same (seed, offset), same advance of the generator -- for
+    sizes below, at and beyond one grid-stride iteration of torch's launch."""
+    from aecf_amd import _lib
+    from aecf_amd.layer import _philox_draw, _ptr, _stream
+    dev = _dev()
+    torch.cuda.manual_seed(4321 + n)
+    torch.rand(3, device=dev)                                   # (a non-zero offset to start from)
+    gen = torch.cuda.default_generators[dev.index or 0]
+    start = gen.get_offset()
+    want = torch.rand(n, device=dev)
+    after_torch = gen.get_offset()
+    gen.set_offset(start)
+    seed, offset, threads = _philox_draw(n, dev)
+    assert offset == start and gen.get_offset() == after_torch, (start, after_torch, gen.get_offset())
+    got = torch.empty(n, device=dev)
+    _lib.check(_lib.load().aecf_philox_uniforms(n, seed, offset, threads, _ptr(got), _stream()), "aecf_philox_uniforms")
+    torch.cuda.synchronize()
+    bad = (got != want).nonzero()
+    assert bad.numel() == 0, (int(bad.numel()), bad[:4].flatten().tolist(), got[bad[:4]].flatten().tolist(),
+                              want[bad[:4]].flatten().tolist(), threads)
+
+
+@pytest.mark.parametrize("dtype,B,M,E,H", [(torch.bfloat16, 5000, 3, 512, 8), (torch.float32, 700, 4, 128, 4),
+                                           (torch.bfloat16, 900, 4, 1024, 8)])
+def test_masks_drawn_in_the_kernel_equal_the_tensor_path(dtype, B, M, E, H):
+    """A training-mode forward that lets the statistics kernel draw its uniforms and one that is handed torch.rand's tensor
+    from the same generator state: identical masks, weights, entropies, outputs; the generator ends at the same offset."""
+    import aecf_amd
+    from aecf_amd import layer
+    dev = _dev()
+    torch.manual_seed(B + E)
+    query, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=0.4, num_heads=H)
+    pool = pool.to(dev, dtype).train()
+    query = query.detach().to(dev, dtype)
+    x = (torch.randn(B, M, E, device=dev) * torch.linspace(0.5, 3.0, M, device=dev).view(1, M, 1)).to(dtype)
+    gen = torch.cuda.default_generators[dev.index or 0]
+    torch.cuda.manual_seed(99)
+    out_k, info_k = pool(query.expand(B, -1, -1), x, return_info=True)
+    off_k = gen.get_offset()
+    torch.cuda.manual_seed(99)
+    layer._DRAW_IN_KERNEL = False
+    try:
+        out_t, info_t = pool(query.expand(B, -1, -1), x, return_info=True)
+    finally:
+        layer._DRAW_IN_KERNEL = True
+    assert gen.get_offset() == off_k
+    torch.cuda.manual_seed(99)
+    u = torch.rand(B, 1, M, device=dev)
+    out_u, info_u = pool(query.expand(B, -1, -1), x, return_info=True, uniforms=u)
+    for other_out, other in ((out_t, info_t), (out_u, info_u)):
+        assert torch.equal(out_k, other_out)
+        for k in ("masked_attention_weights", "mask_rate", "entropy", "attention_weights"):
+            assert torch.equal(info_k[k], other[k]), k
+    assert 0.05 < float(info_k["mask_rate"].float().mean()) < 0.95      # (the draw did mask something, and not everything)
+    cm = pool.curriculum_masking
+    a, b = cm.entropy_loss(info_k["entropy"]), cm.entropy_loss(info_u["entropy"].clone())
+    assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b)) + (4e-3 * abs(float(b)) if dtype == torch.bfloat16 else 0.0)
+
+
 @pytest.mark.parametrize("edit", ["mul_", "clamp_", "view_fill_"])
 def test_entropy_partials_are_dropped_after_an_in_place_edit(edit):
     """info['entropy'] carries the forward's partial sums as an attribute; an in-place edit of the tensor
