@@ -151,6 +151,13 @@ void launch_dqp(int dtype, const DqpJob& q, hipStream_t s) {
     else dqp_kernel<F32><<<dim3(grid), dim3(256), 0, s>>>(q);
 }
 
+void launch_reduce_segments(const ReduceSegs& r, hipStream_t s) {
+    int64_t waves = 0;                                   // one wave per 64 elements, segments padded to waves
+    for (int i = 0; i < ReduceSegs::N; ++i) waves += (r.n[i] + 63) / 64;
+    if (waves == 0) return;
+    reduce_segments_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s>>>(r);
+}
+
 // the whole tail of the backward in one launch; a.u = the REDUCED u [H, E]; the segments of r are reduced as by
 // launch_reduce_segments (pass n = 0 for the u segment: it is an input here)
 void launch_finalize_all(int dtype, const FinalizeArgs& a, const ReduceSegs& r, hipStream_t s) {
