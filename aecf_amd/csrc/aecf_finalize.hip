@@ -106,14 +106,16 @@ __device__ __forceinline__ void fin_dquery_block(const FinalizeArgs& p, int kb, 
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int i0 = 0; i0 < E / 32; i0 += 16) {
+    const int npass = E / 32;                                     // rows per row lane (E % 64 == 0: even, any count)
+    for (int i0 = 0; i0 < npass; i0 += 16) {
         float wv[16][8], dq[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int j = rl + 32 * (i0 + i);
+            const bool on = i0 + i < npass;                       // (branch-free: an always-valid row, weight 0 beyond the end)
+            const int j = rl + 32 * (on ? i0 + i : 0);
             X::load4(wq + (int64_t)j * E, wv[i]);
             X::load4(wq + (int64_t)j * E + 4, wv[i] + 4);
-            dq[i] = p.dqp[j];
+            dq[i] = on ? p.dqp[j] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)

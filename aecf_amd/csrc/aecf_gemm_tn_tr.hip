@@ -420,7 +420,9 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
     const unsigned int ldl = (unsigned)EJ * 2u;
     const unsigned int ldr = (unsigned)M_ * (unsigned)E * 2u;
 
-    // pooling role of this thread: batch row prow, 16-byte chunk pc of the 128-feature slice
+    // pooling role of this thread: batch row prow, 16-byte chunk pc of the 128-feature slice.  (Round 4: a mapping that gives
+    // each 8-lane group of the pooled tile's ds_write_b128 two rows x four chunks -- the 128-byte bank window exactly once
+    // instead of the same 64 bytes twice -- measured level, 93-97 us either way: the stores are not on the critical path.)
     const int prow = threadIdx.x >> 4, pc = threadIdx.x & 15;
     const unsigned int prow_off = (unsigned)prow * ldr;
     const unsigned int coff = 8 * pc < kcols ? 16u * pc : 0u;

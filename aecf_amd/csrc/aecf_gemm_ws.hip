@@ -23,6 +23,17 @@
 #include "aecf_kernels.h"
 #include "aecf_tile.h"
 
+// experiment switches (tools/build_variant.sh): LDS operand reads issued this many items ahead of their MFMAs
+#ifndef AECF_WS_PF
+#define AECF_WS_PF 3
+#endif
+#ifndef AECF_VPROJ_PF
+#define AECF_VPROJ_PF 3
+#endif
+#ifndef AECF_DX_PF
+#define AECF_DX_PF 3
+#endif
+
 namespace aecf {
 
 namespace {
@@ -76,6 +87,39 @@ __device__ __forceinline__ void store_cols(unsigned short* dst, const float* v) 
                                                pack_bf16x2(v[6], v[7])};
     } else {
         *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+}
+
+// softmax over M_ scores in registers, for the gated value projections (bf16 path): v_exp_f32 on the base-2 scaled argument
+// and one reciprocal with a Newton step instead of expf / IEEE division (each of which expands to ~12 instructions, three of
+// each per step, in front of the MFMA phase every wave waits for).  Relative error of a weight ~1e-7 (v_exp_f32 is exact to
+// 1 ulp in its range; masked scores are -inf -> exp2 gives 0).  An all-masked row (sum = 0) gives NaN like the reference's.
+template <int M_>
+__device__ __forceinline__ void softmax_fast(float* sc, float mx) {
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < M_; ++m) {
+        sc[m] = __builtin_amdgcn_exp2f((sc[m] - mx) * 1.44269504088896340736f);
+        sum += sc[m];
+    }
+    float inv = __builtin_amdgcn_rcpf(sum);
+    inv = inv * (2.0f - sum * inv);
+#pragma unroll
+    for (int m = 0; m < M_; ++m) sc[m] *= inv;
+}
+
+// the NV consecutive bias values of a lane as ONE load (NV element-wise `bs ? bs[i] : 0` selects made hipcc emit NV branches,
+// each with its own load and s_waitcnt vmcnt(0): eight dependent memory round trips in every launch's prologue)
+template <int NV>
+__device__ __forceinline__ void load_bias(const unsigned short* bs, int col, float* bias) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) bias[j] = 0.f;
+    if (bs) {
+        if (NV == 8) {
+            Tr<BF16>::unpack(*reinterpret_cast<const u32x4*>(bs + col), bias);
+        } else {
+            Tr<BF16>::load4(bs + col, bias);
+        }
     }
 }
 
@@ -144,11 +188,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
         for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = p.w_frag ? wf[ks * 64] : *reinterpret_cast<const u32x4*>(wr + 32 * ks);
     }
     float bias[NV];
-    {
-        const unsigned short* bs = reinterpret_cast<const unsigned short*>(p.bias);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) bias[j] = bs ? X::to_f32(bs[ncol0 + NV * lg + j]) : 0.f;
-    }
+    load_bias<NV>(reinterpret_cast<const unsigned short*>(p.bias), ncol0 + NV * lg, bias);
     const int head = ncol0 / p.hd;                                // VPROJ: the wave's 32 columns lie in one head
 
     // ---- LDS operand addresses: row (tile t: 16 t + r16 | modality m: r16 M + m), chunk (4 ks + lg) ^ r16
@@ -254,15 +294,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
                 sc[m] = a;
                 mx = fmaxf(mx, a);
             }
-            float sum = 0.f;
-#pragma unroll
-            for (int m = 0; m < M_; ++m) { sc[m] = expf(sc[m] - mx); sum += sc[m]; }
+            softmax_fast<M_>(sc, mx);
             const int64_t bq = o0 + r16;
             const bool writer = lg == 0 && ncol0 % p.hd == 0 && bq < o_end;         // first wave of the head, one lane per sample
 #pragma unroll
-            for (int m = 0; m < M_; ++m) {
-                pm[m] = sc[m] / sum;
-                if (writer) const_cast<float*>(p.probs)[(bq * H + head) * M_ + m] = pm[m];
+            for (int m = 0; m < M_; ++m) pm[m] = sc[m];
+            if (writer) {
+                float* dst = const_cast<float*>(p.probs) + (bq * H + head) * M_;
+#pragma unroll
+                for (int m = 0; m < M_; ++m) dst[m] = pm[m];
             }
         }
 
@@ -272,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
         //      The operand reads run PF items ahead of the MFMAs (a ring of PF+1 registers sets, pinned with
         //      sched_group_barrier so the compiler keeps the reads early instead of sinking them next to their use).
         constexpr int NIT = RT * KT;
-        constexpr int PF = 3;
+        constexpr int PF = AECF_WS_PF;
         const char* tb = smem + cur * TILE;
         auto rd = [&](int i) -> u32x4 {
             const int ks = PL ? i / RT : i % KT;
@@ -463,18 +503,22 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
         for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = p.wvt_frag ? wf[ks * 64] : *reinterpret_cast<const u32x4*>(wr + 32 * ks);
 #pragma unroll
         for (int kx = 0; kx < KX; ++kx) {
-            float v[8];
+            // (all eight loads first, from always-valid addresses, THEN the selects: a load inside `if (e < 3 H)` -- a lane-
+            // dependent condition -- made hipcc branch around each one and wait vmcnt(0) behind it: 16 dependent memory round
+            // trips in this prologue, most of the 17 us this kernel cost per launch whatever the batch)
+            float raw[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int e = 32 * kx + 8 * lg + j;               // entry: [0,H) A_hi, [H,2H) A_hi, [2H,3H) A_lo
-                const int h = e < H_ ? e : (e < 2 * H_ ? e - H_ : e - 2 * H_);
-                float a = 0.f;
-                if (e < 3 * H_) {
-                    a = p.a_f32[(int64_t)h * E + n];
-                    const float hi = X::to_f32(X::from_f32(a));
-                    a = e < 2 * H_ ? hi : a - hi;
-                }
-                v[j] = a;
+                const int h = (e < 3 * H_ ? e : 0) % H_;
+                raw[j] = p.a_f32[(int64_t)h * E + n];
+            }
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = 32 * kx + 8 * lg + j;
+                const float hi = X::to_f32(X::from_f32(raw[j]));
+                v[j] = e < 2 * H_ ? hi : (e < 3 * H_ ? raw[j] - hi : 0.f);
             }
             wreg[KT + kx][c] = X::pack(v);
         }
@@ -548,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             }
 
         // value-side term, head by head; operand reads run PF K-steps ahead
-        constexpr int PF = 3;
+        constexpr int PF = AECF_DX_PF;
         auto rd = [&](int ks) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(tb + xaddr[ks & 3] + (ks >> 2) * 256);
         };
@@ -1070,11 +1114,7 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
         for (int ks = 0; ks < KT; ++ks) wreg[ks][c] = p.w_frag ? wf[ks * 64] : *reinterpret_cast<const u32x4*>(wr + 32 * ks);
     }
     float bias[NV];
-    {
-        const unsigned short* bs = reinterpret_cast<const unsigned short*>(p.bias);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) bias[j] = bs ? X::to_f32(bs[ncol0 + NV * lg + j]) : 0.f;
-    }
+    load_bias<NV>(reinterpret_cast<const unsigned short*>(p.bias), ncol0 + NV * lg, bias);
     const int head = ncol0 / p.hd;
     // operand read of (modality m, K-step ks) for this lane's sample: slab ks >> 1, row 16 m + r16, chunk 4 (ks & 1) + lg
     int xoff[KG];
@@ -1139,6 +1179,11 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
         if (more) load_kp(o0 + 16);
         // ---- softmax over the modalities for (this wave's head, this lane's sample); partial sums in wave order
         float pm[M_];
+#ifdef AECF_ABL_NOSOFTMAX
+#pragma unroll
+        for (int m = 0; m < M_; ++m) pm[m] = 0.25f + 0.125f * m;
+        if (false)
+#endif
         {
             const float* gp = gpart + cur * GP;
             float mx = -INFINITY;
@@ -1151,23 +1196,26 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
                 pm[m] = a;
                 mx = fmaxf(mx, a);
             }
-            float sum = 0.f;
-#pragma unroll
-            for (int m = 0; m < M_; ++m) { pm[m] = expf(pm[m] - mx); sum += pm[m]; }
+            softmax_fast<M_>(pm, mx);
             const int64_t bq = o0 + r16;
             const bool writer = lg == 0 && ncol0 % p.hd == 0 && bq < o_end;
+            if (writer) {                                          // ONE masked region (three before, one per modality)
+                float* dst = const_cast<float*>(p.probs) + (bq * H + head) * M_;
 #pragma unroll
-            for (int m = 0; m < M_; ++m) {
-                pm[m] = pm[m] / sum;
-                if (writer) const_cast<float*>(p.probs)[(bq * H + head) * M_ + m] = pm[m];
+                for (int m = 0; m < M_; ++m) dst[m] = pm[m];
             }
         }
         // ---- products: modality-major items, operand reads PF items ahead; the next tile's copy goes out among the first
-        constexpr int NIT = M_ * KT, PF = 3;
+        constexpr int NIT = M_ * KT, PF = AECF_VPROJ_PF;
         const char* tb = smem + cur * TILE;
         auto rd = [&](int i) -> u32x4 {
             const int ks = i % KT, m = i / KT;
+#ifdef AECF_ABL_NOLDSREAD
+            (void)tb;
+            return u32x4{(unsigned)(0x3f803f80u + ks), (unsigned)(0x3f803f80u + m), 0x3f803f80u, (unsigned)lane};
+#else
             return *reinterpret_cast<const u32x4*>(tb + (ks >> 1) * SLAB + m * 16 * SB + xoff[ks & 1]);
+#endif
         };
         f32x4 acc[CT];
 #pragma unroll
@@ -1183,7 +1231,9 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
+#ifndef AECF_ABL_NODMA
             if (i == NIT / 8 && more) issue(o0 + 16, cur ^ 1);
+#endif
             const int ks = i % KT;
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[c]);
@@ -1208,8 +1258,15 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slab of the next tile (and its mask bytes) landed
 #pragma unroll
         for (int m = 0; m < M_; ++m) { asm volatile("" : "+v"(kp_next[m])); kp[m] = p.g_kpm ? kp_next[m] : 0u; }
+#ifndef AECF_ABL_NOSCORES
         if (more) scores(cur ^ 1, gpart + (cur ^ 1) * GP);         // next step's partial scores, from this wave's own slab
+#endif
         const int64_t b = o0 + r16;
+#ifdef AECF_ABL_NOSTORE
+#pragma unroll
+        for (int j = 0; j < NV; ++j) asm volatile("" :: "v"(ov[j]));
+        if (false)
+#endif
         if (b < o_end) {
             if (p.v_out) {
 #pragma unroll

@@ -202,7 +202,8 @@ def test_info_nce_low_temperature_takes_a_form_sized_for_itself(n, d):
     T = 0.02
     g = torch.Generator().manual_seed(n + d)
     za = torch.randn(n, d, generator=g).to(torch.bfloat16)
-    zb = (za.float() * 0.7 + 0.5 * torch.randn(n, d, generator=g)).to(torch.bfloat16)
+    # weakly correlated views: at T = 0.02 a strong positive makes the loss ~0 and its gradient rounding noise on both sides
+    zb = (za.float() * 0.12 + torch.randn(n, d, generator=g)).to(torch.bfloat16)
     # (1) the public operator against float32 math on the same bf16 inputs
     a = za.to(dev).requires_grad_(True)
     b = zb.to(dev).requires_grad_(True)
