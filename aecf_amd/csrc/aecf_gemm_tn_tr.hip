@@ -517,7 +517,9 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // MFMAs of the previous step done; lhs tile + probabilities visible
         if (more1) {
+#ifndef AECF_ABL_TN_NODMA
             issue_dma(base + TRB, cur ^ 1);
+#endif
             load_probs(base + TRB);
         }
         const f32x2* plc = pl + prow * (MAXS * M_);
@@ -531,8 +533,13 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
         for (int m = 0; m < M_; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[m][i]));
+#ifndef AECF_ABL_TN_NOX
         if (more1) load_x(base + TRB);                    // the chunk registers are free again: next step's chunk flies
+#endif
         const int woff = tr_off(prow, pc);
+#ifdef AECF_ABL_TN_NOPOOL
+        if (base == rbeg)
+#endif
 #pragma unroll
         for (int sl = 0; sl < MAXS; ++sl) {
             if (sl < nslots) {
@@ -554,6 +561,9 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // pooled tiles visible
+#ifdef AECF_ABL_TN_NOMMA
+        if (base == rbeg)
+#endif
         mma_phase(cur, nvalid_cur);
     };
 

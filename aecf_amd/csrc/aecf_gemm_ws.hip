@@ -33,6 +33,9 @@
 #ifndef AECF_DX_PF
 #define AECF_DX_PF 3
 #endif
+#ifndef AECF_VPROJ_SPREAD
+#define AECF_VPROJ_SPREAD 0
+#endif
 
 namespace aecf {
 
@@ -571,7 +574,9 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // do rows + stage of this step visible
+#ifndef AECF_ABL_DX_NOSTAGE
         if (o0 + 16 < o_end) load_stage(o0 + 16);                  // (the rows' copy is issued behind the first head's MFMAs, below)
+#endif
         const char* tb = raw + cur * RAW;
         const float* sp = stage + cur * 16 * HMS + r16 * HMS;      // this lane's sample: probs[h][m]
         const char* xq = xtra + cur * XT + r16 * M_ * XROWB + 16 * lg;
@@ -614,10 +619,17 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             }
         };
         head_mma(0, Pc);
+#ifndef AECF_ABL_DX_NODMA
         if (o0 + 16 < o_end) issue(o0 + 16, cur ^ 1);
+#endif
 #pragma unroll
         for (int h = 0; h < H_; ++h) {
             if (h + 1 < H_) head_mma(h + 1, Pn);
+#ifdef AECF_ABL_DX_NOWEIGHT
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[h % M_][c] += Pc[c];
+            if (false)
+#endif
 #pragma unroll
             for (int m = 0; m < M_; ++m) {
                 const float a = sp[h * M_ + m];
@@ -638,8 +650,17 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
         }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next do rows + stage values landed
+#ifndef AECF_ABL_DX_NOSTAGE
         if (o0 + 16 < o_end) park_stage(cur ^ 1);                  // the other buffer: nobody reads it during this step
+#endif
         const int64_t b = o0 + r16;
+#ifdef AECF_ABL_DX_NOSTORE
+#pragma unroll
+        for (int m = 0; m < M_; ++m)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) asm volatile("" :: "v"(acc[m][c]));
+        if (false)
+#endif
         if (b < o_end) {
 #pragma unroll
             for (int m = 0; m < M_; ++m) {
@@ -1404,22 +1425,22 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
     const char* asrc = reinterpret_cast<const char*>(p.a);
     // this wave's copy of a tile: piece i, lane l -> slab row 8 i + (l >> 3) = 16 m + sample, physical chunk l & 7
     const unsigned int row_pitch = (unsigned)K * 2u;               // bytes of one (sample, modality) row
-    auto issue = [&](int64_t o0, int buf) {
+    auto issue_piece = [&](int64_t o0, int buf, int i) {
         const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
         const char* src = asrc + o0 * M_ * (int64_t)row_pitch + SB * w;
-        char* dst0 = smem + buf * TILE + w * SLAB;
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int rho = 8 * i + (lane >> 3), m = rho >> 4, b = rho & 15;
-            const int bc = b < ov ? b : ov - 1;
-            const unsigned int voff = (unsigned)(bc * M_ + m) * row_pitch + (unsigned)(((lane & 7) ^ (b & 7)) << 4);
-            const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(dst0 + 1024 * i);
+        const int rho = 8 * i + (lane >> 3), m = rho >> 4, b = rho & 15;
+        const int bc = b < ov ? b : ov - 1;
+        const unsigned int voff = (unsigned)(bc * M_ + m) * row_pitch + (unsigned)(((lane & 7) ^ (b & 7)) << 4);
+        const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(smem + buf * TILE + w * SLAB + 1024 * i);
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"      // m0 is named as a clobber on purpose
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst)
-                         : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst)
+                     : "memory", "m0");
 #pragma clang diagnostic pop
-        }
+    };
+    auto issue = [&](int64_t o0, int buf) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) issue_piece(o0, buf, i);
     };
     issue(o_beg, 0);
 
@@ -1552,7 +1573,13 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
         for (int i = 0; i < NIT; ++i) {
             if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
 #ifndef AECF_ABL_NODMA
+#if AECF_VPROJ_SPREAD > 0
+            // the slab's pieces one at a time, AECF_VPROJ_SPREAD items apart (a copy instruction costs its wave 100-200 issue cycles)
+            if (more && i >= NIT / 8 && (i - NIT / 8) % AECF_VPROJ_SPREAD == 0 && (i - NIT / 8) / AECF_VPROJ_SPREAD < NDMA)
+                issue_piece(o0 + 16, cur ^ 1, (i - NIT / 8) / AECF_VPROJ_SPREAD);
+#else
             if (i == NIT / 8 && more) issue(o0 + 16, cur ^ 1);
+#endif
 #endif
             const int ks = i % KT;
 #pragma unroll

@@ -50,7 +50,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16
-PROFILE_TAG = "r03"              # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
+PROFILE_TAG = "r04"              # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
 STAGE_PASS_STEPS = 30            # steps of the per-stage HIP-event pass (roofline), run AFTER the timed region (warm)
 SETTLE_STEPS = 30                # untimed steps of a fresh process before the W warm-up steps (stated in the line) ...
 SETTLE_SECONDS = 2.0             # ... continued until the process has been on the GPU this long: the host's launch path gets ~25 %

@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r02     -> gpurun_out/r02_{c2,c3,c5}_{bench.json,traffic.json}, r02_c2_kernel_stats.csv
 # rocprofv3 counter passes are separate runs (FETCH_SIZE / WRITE_SIZE do not fit one pass), kernel-trace only.
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out
 mkdir -p $out
