@@ -184,7 +184,7 @@ const char* aecf_status_string(int status) {
 
 const char* aecf_pool_stage_name(int backward, int stage) {
     static const char* fwd[AECF_FWD_STAGES] = {"prep", "gate", "vproj", "outproj"};
-    static const char* bwd[AECF_BWD_STAGES] = {"prep", "dout", "dw_out", "dscore", "dx", "dw_v", "u", "finalize"};
+    static const char* bwd[AECF_BWD_STAGES] = {"prep", "dout", "dw_out", "dscore", "u", "dx", "dw_v", "finalize"};
     if (stage < 0) return nullptr;
     if (!backward) return stage < AECF_FWD_STAGES ? fwd[stage] : nullptr;
     return stage < AECF_BWD_STAGES ? bwd[stage] : nullptr;
@@ -485,6 +485,20 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     else if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
         launch_bwd_g(d->dtype, g2, false, s);
     mark(ev, 4, s);
+
+    // dW_v = do^T pooled, db_v = colsum(do), u = ds^T x
+    GemmTnArgs t2;
+    t2.lhs = dobuf; t2.rhs = a->x; t2.probs = a->saved_probs; t2.dsbuf = dsbuf; t2.out = (float*)(ws + L.slab_v);
+    t2.colsum = (float*)(ws + L.cs_v); t2.u = (float*)(ws + L.u_slab); t2.B = B; t2.M = M; t2.E = E; t2.H = H;
+    t2.hd = hd; t2.Ej = 0; t2.splits = L.splits; t2.rows_per_split = L.rows_per_split; t2.pooled = 1;
+    t2.u_splits = L.u_splits; t2.u_rows_per_split = L.u_rows_per_split;
+    // the key-side batch reduction u = ds^T x as its own pass over x where the score-gradient kernel did not form it: BEFORE
+    // the dx kernel (round 4; it needs ds and x only), so that dx can add its slabs up like the fused kernel's
+    if (!dsu_chunks) {
+        t2.parts = 2;
+        launch_gemm_tn(d->dtype, t2, s);
+    }
+    mark(ev, 5, s);
     // input gradient: here, or -- when the caller wants to be told the moment the parameter gradients are final -- last
     const bool dx_last = a->param_grads_event != nullptr;
     // ... and then with a few CUs left free: the dx kernel otherwise takes every CU's whole register file for its one
@@ -494,20 +508,14 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     // where the weight-stationary dx kernel runs between the score gradient and the finalize launch, it also adds up the
     // u slabs (a side job of its weight prologue): the finalize launch then depends on no reduction launch
     bool u_reduced = false;
-    if (dsu_chunks && !dx_last) { g2.u_slab_in = (const float*)(ws + L.u_slab); g2.u_out = u; g2.u_nslab = dsu_chunks; }
+    if (!dx_last) { g2.u_slab_in = (const float*)(ws + L.u_slab); g2.u_out = u; g2.u_nslab = dsu_chunks ? dsu_chunks : L.u_splits; }
     auto run_dx = [&]() {
         if (d->dtype == AECF_BF16 && launch_dx_ws(g2, s)) { u_reduced = g2.u_slab_in != nullptr; return; }
         launch_bwd_g(d->dtype, g2, true, s);
     };
     if (!dx_last) run_dx();
-    mark(ev, 5, s);
+    mark(ev, 6, s);
 
-    // dW_v = do^T pooled, db_v = colsum(do), u = ds^T x
-    GemmTnArgs t2;
-    t2.lhs = dobuf; t2.rhs = a->x; t2.probs = a->saved_probs; t2.dsbuf = dsbuf; t2.out = (float*)(ws + L.slab_v);
-    t2.colsum = (float*)(ws + L.cs_v); t2.u = (float*)(ws + L.u_slab); t2.B = B; t2.M = M; t2.E = E; t2.H = H;
-    t2.hd = hd; t2.Ej = 0; t2.splits = L.splits; t2.rows_per_split = L.rows_per_split; t2.pooled = 1;
-    t2.u_splits = L.u_splits; t2.u_rows_per_split = L.u_rows_per_split;
     t2.parts = 1;
     // dq' = scale W_k u (every remaining gradient of the tail hangs on it) rides in this launch where u is already reduced
     DqpJob dq;
@@ -515,11 +523,6 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     const bool dqp_rides = u_reduced && d->dtype == AECF_BF16;
     if (dqp_rides) t2.dq = dq;
     launch_gemm_tn(d->dtype, t2, s);
-    mark(ev, 6, s);
-    if (!dsu_chunks) {
-        t2.parts = 2;
-        launch_gemm_tn(d->dtype, t2, s);
-    }
     mark(ev, 7, s);
 
     ReduceSegs rs;

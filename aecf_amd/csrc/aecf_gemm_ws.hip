@@ -653,6 +653,9 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
 #ifndef AECF_ABL_DX_NOSTAGE
         if (o0 + 16 < o_end) park_stage(cur ^ 1);                  // the other buffer: nobody reads it during this step
 #endif
+        // (round 4, measured and dropped: the step's stores -- 16 of this kernel's 78 us by ablation, profiles/r04_c2_dx_ablation.txt --
+        //  packed and issued one at a time behind the NEXT step's first heads' MFMAs, with and without a mask branch around
+        //  them: 91-94 us against 76-80 -- a store inside the head pipeline costs more than eight waves storing at once here)
         const int64_t b = o0 + r16;
 #ifdef AECF_ABL_DX_NOSTORE
 #pragma unroll

@@ -179,7 +179,7 @@ typedef struct aecf_pool_bwd_args {
 } aecf_pool_bwd_args;
 
 #define AECF_FWD_STAGES 4   /* prep, gate, vproj, outproj */
-#define AECF_BWD_STAGES 8   /* prep, dout, dw_out, dscore, dx, dw_v, u, finalize */
+#define AECF_BWD_STAGES 8   /* prep, dout, dw_out, dscore, u, dx, dw_v, finalize */
 
 int aecf_abi_version(void);
 /* name of forward (backward == 0) or backward stage i, or NULL when out of range */

@@ -9,10 +9,10 @@ STAGE = [  # (regex on the kernel name, stage)
     (r"vproj_slab_kernel", "fwd.vproj"),
     (r"gemm_ws_kernel<\d+, 0,", "plain_nt"), (r"gemm_nt_kernel", "plain_nt"),
     (r"gemm_tn_tr_kernel<1, false", "bwd.dw_out"),
-    (r"dscore_v_kernel", "bwd.dscore"), (r"dsu_ws_kernel", "bwd.dscore"), (r"row_fwd_kernel", "fwd.vproj"),
+    (r"dscore_v_kernel", "bwd.dscore"), (r"dsu_ws_kernel|dsu_slab_kernel", "bwd.dscore"), (r"row_fwd_kernel", "fwd.vproj"),
     (r"dx_ws2?_kernel", "bwd.dx"), (r"bwd_g_kernel", "bwd.dx"),
     (r"gemm_tn_tr_kernel<\d+, true", "bwd.dw_v"), (r"gemm_tn_tr_wide_kernel", "bwd.dw_v"), (r"gemm_tn_u_kernel|u_stream_kernel", "bwd.u"), (r"gemm_tn_kernel", "bwd.dw_v"),
-    (r"reduce_segments_kernel|fin_outer_kernel|fin_dquery_kernel", "bwd.finalize"),
+    (r"reduce_segments_kernel|fin_outer_kernel|fin_dquery_kernel|finalize_all_kernel|dqp_kernel", "bwd.finalize"),
     (r"prep_all_kernel", "prep"),
 ]
 
