@@ -10,6 +10,7 @@
 //   y       = o W_o^T + b_o                                                         gemm_nt
 // The K projection never materialises; the V projection runs once per sample instead of once per
 // (sample, modality).
+#include <type_traits>
 #include "aecf_kernels.h"
 
 namespace aecf {
@@ -92,7 +93,6 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
     typedef typename X::elem elem;
     __shared__ float red[4][64];
     __shared__ float qsl[1024];
-    __shared__ elem tile[32][33];
     const int nA = (E / 64) * HPAD;
     int id = blockIdx.x;
     if (id < nA) {
@@ -110,14 +110,29 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
                 const int j = h * hd + jj;
                 const elem* wr = w_in + (int64_t)j * E + part * qlen;
                 const elem* qr = q + part * qlen;
+                // (pieces in batches of 8 / 2, all of a batch's loads in flight before the first use: as a plain loop hipcc
+                //  waited for every piece in turn -- E / 32 dependent memory round trips, most of this launch's 26 us at E = 1024;
+                //  the arithmetic order is unchanged: one fmaf chain over kk)
                 float a = 0.f;
-                for (int kk = 0; kk < qlen; kk += X::EPL) {
-                    float wv[X::EPL], qv[X::EPL];
-                    X::unpack(X::load(wr + kk), wv);
-                    X::unpack(X::load(qr + kk), qv);
+                int kk = 0;
+                auto batch = [&](auto nb) {
+                    constexpr int NB = decltype(nb)::value;
+                    typename X::frag wf[NB], qf[NB];
 #pragma unroll
-                    for (int e = 0; e < X::EPL; ++e) a = fmaf(wv[e], qv[e], a);
-                }
+                    for (int i = 0; i < NB; ++i) { wf[i] = X::load(wr + kk + X::EPL * i); qf[i] = X::load(qr + kk + X::EPL * i); }
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        float wv[X::EPL], qv[X::EPL];
+                        X::unpack(wf[i], wv);
+                        X::unpack(qf[i], qv);
+#pragma unroll
+                        for (int e = 0; e < X::EPL; ++e) a = fmaf(wv[e], qv[e], a);
+                    }
+                    kk += X::EPL * NB;
+                };
+                while (kk + 8 * X::EPL <= qlen) batch(std::integral_constant<int, 8>{});
+                while (kk + 2 * X::EPL <= qlen) batch(std::integral_constant<int, 2>{});
+                while (kk < qlen) batch(std::integral_constant<int, 1>{});
                 a += __shfl_xor(a, 1, 64);
                 a += __shfl_xor(a, 2, 64);
                 if (part == 0) {
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
         return;
     }
     id -= nA;
-    const int nt = (E / 32) * (E / 32);
+    const int nt = (E / 64) * (E / 64);
     const int ntr = (t_src0 ? nt : 0) + (t_src1 ? nt : 0);
     if (id >= ntr) {
         // fragment-major copies for the weight-stationary kernels (bf16): chunk ((WG*CT + c)*KT + ks)*64 + lane holds the
@@ -165,25 +180,66 @@ __global__ __launch_bounds__(256) void prep_all_kernel(const typename Tr<T>::ele
             u32x4 v;
             if (!fj.transposed[job]) {
                 v = *reinterpret_cast<const u32x4*>(src + (int64_t)n * E + k0);
-            } else {                                              // W^T[n][k0 + j] = W[k0 + j][n]
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    v[d] = (unsigned)src[(int64_t)(k0 + 2 * d) * E + n] | ((unsigned)src[(int64_t)(k0 + 2 * d + 1) * E + n] << 16);
+                reinterpret_cast<u32x4*>(fj.dst[job])[chunk] = v;
             }
-            reinterpret_cast<u32x4*>(fj.dst[job])[chunk] = v;
+        }
+        if (job < fj.n && fj.transposed[job]) {                   // (block-uniform: a block lies inside one job)
+            // W^T[n][k0 + j] = W[k0 + j][n]: the block's 256 chunks are 4 K-steps (128 rows k) of ONE (WG, c) column set (KT % 4 == 0),
+            // i.e. a [128 k][32 n] (CT = 2) / [128][16] piece of W: staged through LDS with 16-byte loads of whole 64- / 32-byte
+            // row pieces, each thread then picks its 8 elements out of LDS (round 1-3: eight scattered 2-byte global loads per
+            // thread -- most of this launch's time at E = 1024)
+            __shared__ __attribute__((aligned(16))) unsigned short ttile[128][40];
+            const int CT = E <= 512 ? 2 : 1, KT = E / 32;
+            const int chunk0 = (id - job * bpj) * 256;
+            const int ks0 = (chunk0 >> 6) % KT, rest0 = (chunk0 >> 6) / KT;
+            const int c0 = rest0 % CT, WG0 = rest0 / CT;
+            const int nb = CT == 2 ? 32 * WG0 : 16 * WG0;
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(fj.src[job]);
+            const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+            const unsigned short* gp = src + (int64_t)(32 * ks0 + row) * E + nb + (CT == 2 ? 16 : 8) * half;
+            if (CT == 2) {
+                const u32x4 a0 = *reinterpret_cast<const u32x4*>(gp), a1 = *reinterpret_cast<const u32x4*>(gp + 8);
+                *reinterpret_cast<u32x4*>(&ttile[row][16 * half]) = a0;
+                *reinterpret_cast<u32x4*>(&ttile[row][16 * half + 8]) = a1;
+            } else {
+                *reinterpret_cast<u32x4*>(&ttile[row][8 * half]) = *reinterpret_cast<const u32x4*>(gp);
+            }
+            __syncthreads();
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, lg = lane >> 4;
+            const int nl = CT == 2 ? 8 * (r16 >> 2) + 4 * c0 + (r16 & 3) : r16;
+            const int kl = 32 * wv + 8 * lg;
+            u32x4 v;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) v[d] = (unsigned)ttile[kl + 2 * d][nl] | ((unsigned)ttile[kl + 2 * d + 1][nl] << 16);
+            reinterpret_cast<u32x4*>(fj.dst[job])[chunk0 + threadIdx.x] = v;
         }
         return;
     }
+    // 64 x 64 tiles (E % 64 == 0), whole 16-byte pieces on both global sides: thread = (row t >> 2, quarter t & 3) moves
+    // 16 elements of its row in, and 16 elements of its transposed row out (round 1-3: 32 x 32 tiles through 2-byte / 4-byte
+    // global accesses -- most of this launch's 26 us at E = 1024)
     const elem* src = id < nt ? t_src0 : t_src1;
     elem* dst = id < nt ? t_dst0 : t_dst1;
     if (id >= nt) id -= nt;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int j0 = (id / (E / 32)) * 32, k0 = (id % (E / 32)) * 32;
-    for (int r = ty; r < 32; r += 8)
-        if (j0 + r < E && k0 + tx < E) tile[r][tx] = src[(int64_t)(j0 + r) * E + k0 + tx];
+    constexpr int V = 16 / X::BYTES;                               // elements per 16-byte piece
+    __shared__ __attribute__((aligned(16))) elem tt[64][64 + V];
+    const int row = threadIdx.x >> 2, qt = threadIdx.x & 3;
+    const int j0 = (id / (E / 64)) * 64, k0 = (id % (E / 64)) * 64;
+    {
+        const elem* g = src + (int64_t)(j0 + row) * E + k0 + 16 * qt;
+#pragma unroll
+        for (int v = 0; v < 16 / V; ++v)
+            *reinterpret_cast<u32x4*>(&tt[row][16 * qt + V * v]) = *reinterpret_cast<const u32x4*>(g + V * v);
+    }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8)
-        if (k0 + r < E && j0 + tx < E) dst[(int64_t)(k0 + r) * E + j0 + tx] = tile[tx][r];
+    {
+        __attribute__((aligned(16))) elem o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = tt[16 * qt + e][row];
+        elem* g = dst + (int64_t)(k0 + row) * E + j0 + 16 * qt;
+#pragma unroll
+        for (int v = 0; v < 16 / V; ++v) *reinterpret_cast<u32x4*>(g + V * v) = *reinterpret_cast<const u32x4*>(&o[V * v]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -361,7 +417,7 @@ void launch_prep_amat(int dtype, const void* w_in, const float* qs, float* a_f32
 void launch_prep_all(int dtype, const void* w_in, const void* b_in, const void* query, float scale, float* qs, float* a_f32,
                      void* a_hi, void* a_lo, const void* t_src0, void* t_dst0, const void* t_src1, void* t_dst1, int E,
                      int H, const FragJobs& fj, hipStream_t s) {
-    const int nt = (E / 32) * (E / 32);
+    const int nt = (E / 64) * (E / 64);
     const int nfrag = dtype == 0 ? fj.n * ((E * E / 8 + 255) / 256) : 0;
     dim3 grid((E / 64) * HPAD + (t_src0 ? nt : 0) + (t_src1 ? nt : 0) + nfrag), block(256);
     if (dtype == 0)
