@@ -18,6 +18,7 @@ AECF_BF16 = 0
 AECF_F32 = 1
 AECF_PRECISE = 1
 AECF_DRAW_UNIFORMS = 2
+AECF_HILO_GRADS = 4
 AECF_FWD_STAGES = 4
 AECF_BWD_STAGES = 8
 
@@ -55,6 +56,7 @@ class PoolFwdArgs(Structure):
         ("info_target_entropy", c_void_p), ("target_entropy_value", c_float), ("flags", c_int32),
         ("ent_loss_partial", c_void_p),
         ("philox_seed", c_uint64), ("philox_offset", c_uint64), ("philox_threads", c_uint32), ("ent_loss", c_void_p),
+        ("saved_o_lo", c_void_p),
     ]
 
 
@@ -68,6 +70,7 @@ class PoolBwdArgs(Structure):
         ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
         ("grad_dtype", c_int32), ("flags", c_int32), ("saved_prep", c_void_p), ("param_grads_event", c_void_p),
+        ("saved_o_lo", c_void_p),
     ]
 
 
@@ -101,6 +104,7 @@ _SYMBOLS = [
     ("aecf_pool_fwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_bwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_prep_bytes", c_size_t, [POINTER(PoolDesc)]),
+    ("aecf_pool_hilo_bwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_wants_saved_v", c_int, [POINTER(PoolDesc)]),
     ("aecf_pool_precise_workspace_bytes", c_size_t, [POINTER(PoolDesc), c_int]),
     ("aecf_philox_uniforms", c_int, [c_int64, c_uint64, c_uint64, c_uint32, c_void_p, c_void_p]),

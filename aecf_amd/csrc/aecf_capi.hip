@@ -63,11 +63,11 @@ PrepWs prep_layout(const aecf_pool_desc* d) {
 
 struct BwdWs {
     PrepWs prep;
-    size_t dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, dq_part, total;
+    size_t dobuf, dsbuf, slab_o, slab_v, cs_o, cs_v, u_slab, u, dqp, dq_part, do_lo, total;
     int splits, u_splits, u_splits_cap;
     int64_t rows_per_split, u_rows_per_split;
 };
-BwdWs bwd_layout(const aecf_pool_desc* d) {
+BwdWs bwd_layout(const aecf_pool_desc* d, bool hilo = false) {
     BwdWs w;
     const size_t E = d->embed_dim, es = esize(d->dtype);
     const size_t B = (size_t)d->batch;
@@ -95,15 +95,18 @@ BwdWs bwd_layout(const aecf_pool_desc* d) {
     size_t off = w.prep.total;
     w.dobuf = off;  off = align_up(off + B * E * es);
     w.dsbuf = off;  off = align_up(off + B * d->num_heads * d->modalities * 4);
-    w.slab_o = off; off = align_up(off + (size_t)S * E * E * 4);
-    w.slab_v = off; off = align_up(off + (size_t)S * E * E * 4);
+    // AECF_HILO_GRADS: dW_o from two launches (o hi, o lo), dW_v from three (hi hi, hi lo, lo hi), db_v from two: their slabs
+    // line up behind each other and the reduction adds them all
+    w.slab_o = off; off = align_up(off + (size_t)(hilo ? 2 : 1) * S * E * E * 4);
+    w.slab_v = off; off = align_up(off + (size_t)(hilo ? 3 : 1) * S * E * E * 4);
     w.cs_o = off;   off = align_up(off + (size_t)S * E * 4);
-    w.cs_v = off;   off = align_up(off + (size_t)S * E * 4);
+    w.cs_v = off;   off = align_up(off + (size_t)(hilo ? 2 : 1) * S * E * 4);
     w.u_splits_cap = w.u_splits > 256 ? w.u_splits : 256;            // the head-split kernel writes up to 256 slabs
     w.u_slab = off; off = align_up(off + (size_t)w.u_splits_cap * HPAD * E * 4);
     w.u = off;      off = align_up(off + HPAD * E * 4);
     w.dqp = off;    off = align_up(off + E * 4);
     w.dq_part = off; off = align_up(off + (E / 16) * E * 4);
+    w.do_lo = off;  if (hilo) off = align_up(off + B * E * es);
     w.total = off;
     return w;
 }
@@ -229,6 +232,29 @@ int aecf_pool_wants_saved_v(const aecf_pool_desc* d) {
     return 1;
 }
 
+// AECF_HILO_GRADS is built for the bf16 shapes whose value projection runs on the weight-stationary kernel in its
+// per-sample form (the kernels that can write the low part of o and of do)
+static bool hilo_supported(const aecf_pool_desc* d) {
+    if (aecf_pool_check(d) != AECF_OK || d->dtype != AECF_BF16 || env_no_ws()) return false;
+    GemmNtArgs v;
+    v.a = nullptr; v.w = nullptr; v.bias = nullptr; v.c = nullptr; v.probs = nullptr; v.R = d->batch; v.N = d->embed_dim;
+    v.K = d->embed_dim; v.lda = (int64_t)d->modalities * d->embed_dim; v.M = d->modalities; v.H = d->num_heads;
+    v.hd = d->embed_dim / d->num_heads; v.pooled = 1; v.out_f32 = 0; v.v_out = nullptr;
+    if (!gemm_ws_supported(v)) return false;
+    if (d->modalities == 4 && d->embed_dim > 512) return false;         // (the flat-row form has no per-sample o in a lane)
+    GemmNtArgs y = v;
+    y.pooled = 0; y.M = 1; y.lda = d->embed_dim;
+    if (!gemm_ws_supported(y)) return false;
+    BwdGArgs g;                                                         // ... and the score gradient on dsu_ws_kernel (do_hi + do_lo)
+    g.B = d->batch; g.M = d->modalities; g.E = d->embed_dim; g.H = d->num_heads; g.hd = d->embed_dim / d->num_heads;
+    return dsu_ws_chunks(g) > 0;
+}
+
+size_t aecf_pool_hilo_bwd_workspace_bytes(const aecf_pool_desc* d) {
+    if (!hilo_supported(d)) return 0;
+    return bwd_layout(d, true).total;
+}
+
 size_t aecf_pool_prep_bytes(const aecf_pool_desc* d) {
     if (aecf_pool_check(d) != AECF_OK) return 0;
     return prep_layout(d).total;
@@ -301,7 +327,13 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
     v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = precise ? 1 : 0; v.v_out = precise ? nullptr : a->saved_v;
     if (frag) v.w_frag = ws + L.wv_frag;
-    if (env_fused_fwd() && !precise && row_fwd_supported(d->dtype, E, M, H)) {
+    const bool hilo = (a->flags & AECF_HILO_GRADS) != 0;
+    if (hilo) {
+        if (precise || !hilo_supported(d)) return AECF_ERR_UNSUPPORTED;
+        if (!a->saved_o || !a->saved_o_lo) return AECF_ERR_NULL_POINTER;
+        v.c_lo = a->saved_o_lo;
+    }
+    if (env_fused_fwd() && !precise && !hilo && row_fwd_supported(d->dtype, E, M, H)) {
         // ONE kernel from x to y: scores, softmax, statistics, value projection, pooling, out-projection (aecf_row_fwd.hip)
         GemmNtArgs yo;
         yo.a = o; yo.w = a->w_out; yo.bias = a->b_out; yo.c = a->y; yo.probs = nullptr; yo.R = d->batch; yo.N = E; yo.K = E;
@@ -422,7 +454,10 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
         return AECF_ERR_NULL_POINTER;
     if (a->d_entropy && !a->attn_w) return AECF_ERR_NULL_POINTER;
     if (a->grad_dtype != AECF_F32 && !(a->grad_dtype == AECF_BF16 && d->dtype == AECF_BF16)) return AECF_ERR_UNSUPPORTED;
-    const BwdWs L = bwd_layout(d);
+    const bool hilo = (a->flags & AECF_HILO_GRADS) != 0;
+    if (hilo && (!hilo_supported(d) || do_ready)) return AECF_ERR_UNSUPPORTED;
+    if (hilo && !a->saved_o_lo) return AECF_ERR_NULL_POINTER;
+    const BwdWs L = bwd_layout(d, hilo);
     if (a->workspace_bytes < L.total) return AECF_ERR_WORKSPACE;
     char* ws = (char*)a->workspace;
     const int E = d->embed_dim, H = d->num_heads, M = d->modalities, hd = E / H, es = esize(d->dtype);
@@ -459,6 +494,7 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     g.a = a->dy; g.w = wot; g.bias = nullptr; g.c = dobuf; g.probs = nullptr; g.R = B; g.N = E; g.K = E; g.lda = E;
     g.M = 1; g.H = H; g.hd = hd; g.pooled = 0; g.out_f32 = 0; g.v_out = nullptr;
     if (frag) g.w_frag = pb + P.wot_frag;
+    if (hilo) g.c_lo = ws + L.do_lo;
     if (!do_ready) launch_gemm_nt(d->dtype, g, s);
     mark(ev, 2, s);
 
@@ -469,6 +505,11 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     t1.Ej = 0; t1.splits = L.splits; t1.rows_per_split = L.rows_per_split; t1.pooled = 0;
     t1.u_splits = 0; t1.u_rows_per_split = 0;
     launch_gemm_tn(d->dtype, t1, s);
+    if (hilo) {                                       // + dy^T o_lo, into the slabs behind
+        GemmTnArgs t1l = t1;
+        t1l.rhs = a->saved_o_lo; t1l.out = t1.out + (size_t)L.splits * E * E; t1l.colsum = nullptr;
+        launch_gemm_tn(d->dtype, t1l, s);
+    }
     const int gb = a->grad_dtype == AECF_BF16 ? 1 : 0;
     mark(ev, 3, s);
 
@@ -480,6 +521,7 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     // score gradient.  bf16 shapes of the head-split weight-stationary kernel: ds AND u = ds^T x in one pass over (do, x),
     // nothing saved by the forward; otherwise from the saved V (memory-bound dot), else by recomputing W_v^T do per head
     int dsu_chunks = 0;
+    if (hilo) g2.do_lo = ws + L.do_lo;                // (read by dsu_ws_kernel only: other shapes keep the default key-side accuracy)
     if (d->dtype == AECF_BF16 && !env_no_ws() && dsu_ws_chunks(g2) > 0 && dsu_ws_chunks(g2) <= L.u_splits_cap)
         dsu_chunks = launch_dsu_ws(g2, (float*)(ws + L.u_slab), s);
     else if (!(a->saved_v && launch_dscore_v(d->dtype, g2, a->saved_v, s)))
@@ -523,11 +565,22 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     const bool dqp_rides = u_reduced && d->dtype == AECF_BF16;
     if (dqp_rides) t2.dq = dq;
     launch_gemm_tn(d->dtype, t2, s);
+    if (hilo) {
+        // dW_v = do_hi^T pooled_hi (above) + do_hi^T pooled_lo + do_lo^T pooled_hi; db_v = colsum(do_hi) + colsum(do_lo)
+        GemmTnArgs t2b = t2;
+        t2b.dq = DqpJob(); t2b.pool_lo = 1; t2b.out = t2.out + (size_t)L.splits * E * E; t2b.colsum = nullptr;
+        launch_gemm_tn(d->dtype, t2b, s);
+        GemmTnArgs t2c = t2;
+        t2c.dq = DqpJob(); t2c.lhs = ws + L.do_lo; t2c.out = t2.out + (size_t)2 * L.splits * E * E;
+        t2c.colsum = t2.colsum + (size_t)L.splits * E;
+        launch_gemm_tn(d->dtype, t2c, s);
+    }
     mark(ev, 7, s);
 
     ReduceSegs rs;
     for (int i = 0; i < ReduceSegs::N; ++i) rs.splits[i] = L.splits;
     rs.splits[4] = dsu_chunks ? dsu_chunks : L.u_splits;
+    if (hilo) { rs.splits[0] = 2 * L.splits; rs.splits[2] = 3 * L.splits; rs.splits[3] = 2 * L.splits; }
     const size_t gsz = gb ? 2 : 4;                                    // bytes per parameter-gradient element
     for (int i = 0; i < ReduceSegs::N; ++i) rs.dst_bf16[i] = gb;
     rs.dst_bf16[4] = 0;                                               // u stays float32 (internal)

@@ -284,7 +284,13 @@ __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(Gemm
                         }
                         u32x4 o;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                        for (int i = 0; i < 4; ++i) {
+                            if (p.pool_lo) {                       // (launch-uniform) the low parts of the pooled values
+                                pv[i][0] -= X::to_f32(X::from_f32(pv[i][0]));
+                                pv[i][1] -= X::to_f32(X::from_f32(pv[i][1]));
+                            }
+                            o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                        }
                         *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
                     }
                 }
@@ -555,7 +561,13 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
                 }
                 u32x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                for (int i = 0; i < 4; ++i) {
+                            if (p.pool_lo) {                       // (launch-uniform) the low parts of the pooled values
+                                pv[i][0] -= X::to_f32(X::from_f32(pv[i][0]));
+                                pv[i][1] -= X::to_f32(X::from_f32(pv[i][1]));
+                            }
+                            o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                        }
                 *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
             }
         }

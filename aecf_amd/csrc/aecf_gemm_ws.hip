@@ -83,6 +83,16 @@ __device__ __forceinline__ void store_cols_f32(float* dst, const float* v) {
     *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
     if (CT == 2) *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
+// the bf16 low parts of the same columns: v - float(bf16(v)), rounded to bf16
+template <int CT>
+__device__ __forceinline__ void store_cols(unsigned short* dst, const float* v);
+template <int CT>
+__device__ __forceinline__ void store_cols_lo(unsigned short* dst, const float* v) {
+    float lo[4 * CT];
+#pragma unroll
+    for (int j = 0; j < 4 * CT; ++j) lo[j] = v[j] - Tr<BF16>::to_f32(Tr<BF16>::from_f32(v[j]));
+    store_cols<CT>(dst, lo);
+}
 template <int CT>
 __device__ __forceinline__ void store_cols(unsigned short* dst, const float* v) {
     if (CT == 2) {
@@ -393,6 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
                     if (row < o_end) {
                         if (p.out_f32) store_cols_f32<CT>(reinterpret_cast<float*>(p.c) + row * N + ncol0 + NV * lg, v);
                         else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + NV * lg, v);
+                        if (p.c_lo) store_cols_lo<CT>(reinterpret_cast<unsigned short*>(p.c_lo) + row * N + ncol0 + NV * lg, v);
                     }
                 } else {
                     if (p.v_out && row < o_end)
@@ -419,6 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
                 }
                 if (p.out_f32) store_cols_f32<CT>(reinterpret_cast<float*>(p.c) + b * N + ncol0 + NV * lg, ov);
                 else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + NV * lg, ov);
+                if (p.c_lo) store_cols_lo<CT>(reinterpret_cast<unsigned short*>(p.c_lo) + b * N + ncol0 + NV * lg, ov);
             }
         }
     }
@@ -700,7 +712,7 @@ __device__ __forceinline__ float dot2_bf16(unsigned int a, unsigned int b, float
 // columns k (k = ncol0 + 32 (ct >> 1) + 8 lg + 4 (ct & 1) + reg, the trick of the plain kernel's 16-byte stores), so the dot
 // reads x in 16-byte pieces: half the LDS reads of the 8-byte form -- each of them is waited for right in front of its use
 // (the kernel has no registers left to run them ahead: profiles/r01_pmc_notes.md, end of round 3).
-template <int KT, int KJ, int HK, int M_, bool PKDOT, int VAR>
+template <int KT, int KJ, int HK, int M_, bool PKDOT, int VAR, bool HILO = false>
 __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __restrict__ u_slab, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
     constexpr bool WIDE = VAR >= 1;                               // 16-byte dot reads (VAR 0: the 8-byte form of rounds 2-3)
@@ -720,7 +732,8 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     char* xb = smem;                                              // [2][16 M][E] x rows (b, m), 16-byte chunk ^ sample
     char* zp = smem + 2 * XT;                                     // [ZROWS][E] zeros
     char* db = zp + ZROWS * ROWX;                                 // [2][16][JB] do rows, chunk ^ row
-    float* part = reinterpret_cast<float*>(db + 2 * DT);          // [32][HM][16 samples]
+    char* dbl = db + 2 * DT;                                      // HILO: [2][16][JB] low parts of the do rows
+    float* part = reinterpret_cast<float*>(db + (HILO ? 4 : 2) * DT);   // [32][HM][16 samples]
     unsigned short* dsh = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(part) + NPART * PSTR * 4);     // [16][DSROW] bf16 hi
     unsigned short* dsl = dsh + 16 * DSROW;                                                                          // [16][DSROW] bf16 lo
 
@@ -737,10 +750,12 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
 
     const char* dsrc = reinterpret_cast<const char*>(p.dobuf) + (int64_t)jbase * 2;
     const char* xsrc = reinterpret_cast<const char*>(p.x);
+    const char* dlsrc = HILO ? reinterpret_cast<const char*>(p.do_lo) + (int64_t)jbase * 2 : dsrc;
     auto issue = [&](int64_t o0, int buf) {
         const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
         ws_dma_rows_asm<KT, 16 * M_, M_>(xsrc + o0 * M_ * (int64_t)ROWX, (unsigned)ROWX, ov * M_, xb + buf * XT);
         ws_dma_rows_asm<KJ, 16, 1>(dsrc + o0 * (int64_t)ROWX, (unsigned)ROWX, ov, db + buf * DT);
+        if (HILO) ws_dma_rows_asm<KJ, 16, 1>(dlsrc + o0 * (int64_t)ROWX, (unsigned)ROWX, ov, dbl + buf * DT);
     };
     // what the DMA never writes and the MFMAs still read: the zero page, the ds operand arrays
     for (int i = threadIdx.x; i < ZROWS * ROWX / 16; i += 512) reinterpret_cast<u32x4*>(zp)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -860,6 +875,11 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                     const u32x4 bf = *reinterpret_cast<const u32x4*>(tb + daddr[ks & 3] + (ks >> 2) * 256);
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) P[g][ct] = X::mma(wreg[ks][ct], bf, P[g][ct]);
+                    if (HILO) {
+                        const u32x4 bl = *reinterpret_cast<const u32x4*>(dbl + cur * DT + daddr[ks & 3] + (ks >> 2) * 256);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) P[g][ct] = X::mma(wreg[ks][ct], bl, P[g][ct]);
+                    }
                 }
             }
             unsigned int pk[HG][NCT][2];
@@ -1321,8 +1341,10 @@ template <int KT, int KJ, int HK, int M_>
 int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     constexpr int E = 32 * KT, JB = 32 * KJ, HBL = KJ / HK;
     constexpr int XROWS = 16 * M_, ZROWS = (32 * ((XROWS + 31) / 32) - XROWS) > 0 ? 1 : 0;
-    const size_t smem = (size_t)(2 * XROWS + ZROWS) * 2 * E + (size_t)2 * 16 * 2 * JB + (size_t)8 * (16 * HBL * M_) * 4 +
-                        (size_t)2 * 16 * 72 * 2;
+    const size_t smem_base = (size_t)(2 * XROWS + ZROWS) * 2 * E + (size_t)2 * 16 * 2 * JB + (size_t)8 * (16 * HBL * M_) * 4 +
+                             (size_t)2 * 16 * 72 * 2;
+    const bool hilo = a.do_lo && smem_base + (size_t)2 * 16 * 2 * JB <= 160 * 1024;      // (else: the default key-side accuracy)
+    const size_t smem = smem_base + (hilo ? (size_t)2 * 16 * 2 * JB : 0);
     const int groups = E / JB;
     int64_t chunks = 256 / groups;
     if (chunks < 1) chunks = 1;
@@ -1337,6 +1359,12 @@ int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
         kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);                                                      \
         return (int)nchunk;                                                                                                    \
+    }
+    if (hilo) {                                                   // AECF_HILO_GRADS: P from do_hi + do_lo
+        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false, ((KT / 4) % 2 == 0 ? 2 : 0), true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
+        return (int)nchunk;
     }
     if (var == 0) DSU_GO(0)
     if (var == 1) DSU_GO(1)
@@ -1625,6 +1653,7 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
             }
             if (p.out_f32) store_cols_f32<CT>(reinterpret_cast<float*>(p.c) + b * N + ncol0 + NV * lg, ov);
             else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + NV * lg, ov);
+            if (p.c_lo) store_cols_lo<CT>(reinterpret_cast<unsigned short*>(p.c_lo) + b * N + ncol0 + NV * lg, ov);
         }
     }
 }
@@ -1760,7 +1789,7 @@ static int launch_dsu_m(const BwdGArgs& a, float* u_slab, hipStream_t s) {
 int launch_dsu_ws(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     if (dsu_ws_chunks(a) == 0) return 0;
     const int hk = a.hd / 32;
-    if (a.E == 512 && hk == 2 && a.M <= 3 && env_dsu_var() >= 3) {           // the hot shape: wave-private slabs, one barrier per step
+    if (a.E == 512 && hk == 2 && a.M <= 3 && env_dsu_var() >= 3 && !a.do_lo) {           // the hot shape: wave-private slabs, one barrier per step
         switch (a.M) {
             case 1: return launch_dsu_slab<1>(a, u_slab, s);
             case 2: return launch_dsu_slab<2>(a, u_slab, s);

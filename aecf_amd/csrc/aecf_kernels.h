@@ -89,6 +89,9 @@ struct GemmNtArgs {
     int ent_nblk = 0;
     float ent_inv_n = 0.f;
     void* ent_loss = nullptr;         // [1] dtype
+    // weight-stationary kernel only, optional: the bf16 LOW part of the output, c_lo = bf16(C - float(bf16(C))), same shape as c
+    // (AECF_HILO_GRADS: the weight-gradient products then run on hi + lo operand pairs)
+    void* c_lo = nullptr;
 };
 void launch_gemm_nt(int dtype, const GemmNtArgs& a, hipStream_t s);
 void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s);   // pooled == 1 path
@@ -125,6 +128,9 @@ struct BwdGArgs {
     const float* u_slab_in = nullptr;
     float* u_out = nullptr;
     int u_nslab = 0;
+    // AECF_HILO_GRADS (dsu_ws_kernel): the low part of dobuf -- the score gradient then forms P from do_hi + do_lo, so that the
+    // key-side reduction u (dW_q, dW_k, db_q, dquery hang on it) is float32-accurate as well
+    const void* do_lo = nullptr;
 };
 void launch_bwd_g(int dtype, const BwdGArgs& a, bool dx, hipStream_t s);
 // score gradient from the saved value projections: da[b,h,m] = do_h[b] . V_h[b,m]  (memory-bound, one wave per sample)
@@ -159,6 +165,7 @@ struct GemmTnArgs {
     int pooled;
     int parts = 0;            // pooled: 0 = main product + u, 1 = main product only, 2 = u only (separate stage timing)
     DqpJob dq;                // bf16 transposed-read kernels only: side job of the launch (aecf_common.h); w_k == null: off
+    int pool_lo = 0;          // pooled bf16 kernels: feed the MFMA the LOW part of the pooled rows, bf16(P - float(bf16(P)))
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b64_tr_b16 form (main product only)

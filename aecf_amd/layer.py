@@ -94,6 +94,11 @@ def _device_props(index: int) -> Tuple[int, int]:
     return p
 
 
+# AECF_HILO_GRADS (include/aecf_hip.h): the weight-gradient products of the fused backward on bf16 hi + lo operand pairs, so
+# that float32-stored parameter gradients are float32-accurate (a verification / high-accuracy mode: three more launches of
+# the batch-reduction kernels per step).  Off by default; shapes the flag is not built for run the default path.
+_HILO_GRADS = False
+
 # in-kernel draw of the curriculum mask's uniforms (no torch.rand launch, no [B,M] tensor); tests switch it off to compare
 _DRAW_IN_KERNEL = True
 
@@ -220,6 +225,13 @@ class _PoolFunction(torch.autograd.Function):
                 ent_loss = torch.empty(1, dtype=dt, device=dev)
             side["ent_partial"] = (ent_partial, B, float(target_value), ent_loss)
         flags = 0
+        saved_o_lo = None
+        hilo_ws = 0
+        if _HILO_GRADS and need_bwd and dt == torch.bfloat16:
+            hilo_ws = lib.aecf_pool_hilo_bwd_workspace_bytes(ctypes.byref(desc))
+            if hilo_ws > 0:
+                saved_o_lo = torch.empty(B, E, dtype=dt, device=dev)
+                flags |= _lib.AECF_HILO_GRADS
         ph_seed = ph_off = ph_threads = 0
         if philox is not None and mask_mode == 1 and uniforms is None:
             ph_seed, ph_off, ph_threads = philox
@@ -233,11 +245,11 @@ class _PoolFunction(torch.autograd.Function):
             None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd),
             _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate), _ptr(saved_prep),
             _ptr(i_target), 0.0 if target_value is None else float(target_value), flags, _ptr(ent_partial),
-            ph_seed, ph_off, ph_threads, _ptr(ent_loss))
+            ph_seed, ph_off, ph_threads, _ptr(ent_loss), _ptr(saved_o_lo))
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
-        ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep)
+        ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep, saved_o_lo)
         ctx.desc = desc
-        ctx.bwd_ws_bytes = bwd_ws_bytes
+        ctx.bwd_ws_bytes = hilo_ws if saved_o_lo is not None else bwd_ws_bytes
         ctx.q_shape = q.shape
         ctx.param_dtypes = (q.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
                             None if b_out is None else b_out.dtype)
@@ -255,7 +267,7 @@ class _PoolFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, d_attn_w, _d_masked, d_entropy, _d_rate, _d_target=None):
         lib = _lib.load()
-        xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep = ctx.saved_tensors
+        xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep, saved_o_lo = ctx.saved_tensors
         desc = ctx.desc
         B, M, E = xc.shape
         dev = xc.device
@@ -290,7 +302,8 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
             _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes,
             None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd),
-            _DTYPES[out_dt], 0, _ptr(saved_prep), None if early is None else early.cuda_event)
+            _DTYPES[out_dt], 0 if saved_o_lo is None else _lib.AECF_HILO_GRADS, _ptr(saved_prep),
+            None if early is None else early.cuda_event, _ptr(saved_o_lo))
         _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")
         flat32 = None
         if keep32:

@@ -413,6 +413,9 @@ def main():
     ap.add_argument("--contrastive", action="store_true",
                     help="configs[2]: add the symmetric InfoNCE against 65536 gathered keys (+ entropy loss) to the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hilo", action="store_true",
+                    help="AECF_HILO_GRADS: weight-gradient products on bf16 hi + lo operand pairs (float32-accurate parameter "
+                         "gradients; a verification / high-accuracy mode, timed for the record)")
     ap.add_argument("--overlap", action="store_true",
                     help="N>1: issue the gradient all-reduce behind the backward's dx kernel on a side stream (dp.GradOverlap: "
                          "EXPERIMENTAL -- never run over RCCL on real multi-GPU hardware by this build; default: one all-reduce "
@@ -420,6 +423,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="(default behaviour; kept for older command lines)")
     args = ap.parse_args()
     globals()["SETTLE_SECONDS"] = args.settle_seconds
+    if args.hilo:
+        from aecf_amd import layer as _layer
+        _layer._HILO_GRADS = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))

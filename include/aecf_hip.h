@@ -137,10 +137,21 @@ typedef struct aecf_pool_fwd_args {
      * call -- max(mean((nan_to_num(H) - target)^2), 0), ref :285-314 -- written by the out-projection launch's first block from
      * the partial sums (no launch of its own; shapes the weight-stationary kernel does not take: one small launch).  NULL = off. */
     void* ent_loss;
+    /* ABI v8, AECF_HILO_GRADS: [B,E] dtype, the LOW part of saved_o -- bf16(o - float(bf16(o))) -- written beside it by the
+     * value projection; hand both to the backward (see aecf_pool_bwd_args.saved_o_lo).  Required with the flag. */
+    void* saved_o_lo;
 } aecf_pool_fwd_args;
 
 #define AECF_PRECISE 1
 #define AECF_DRAW_UNIFORMS 2
+/* AECF_HILO_GRADS (bf16; aecf_pool_hilo_bwd_workspace_bytes(desc) > 0 says the shape is built): the WEIGHT-GRADIENT products
+ * of the backward take both operands as bf16 hi + lo pairs -- dW_o = dy^T (o_hi + o_lo), dW_v = do_hi^T P_hi + do_hi^T P_lo +
+ * do_lo^T P_hi with do = dy W_o and the pooled rows P split where they are formed -- so that float32-stored parameter gradients
+ * are float32-accurate (the bf16 roundings of the two derived operands are what puts the default path's dW at 2-4e-3 of fp32
+ * math).  Everything else (y, dx, the kernels) is the default path.  Set it on BOTH calls.  Cost: three more launches of the
+ * batch-reduction kernels per step (profiles/r04_c2_hilo_time.txt); the backward workspace is the larger
+ * aecf_pool_hilo_bwd_workspace_bytes. */
+#define AECF_HILO_GRADS 4
 
 /* Backward (autograd transpose of the above). */
 typedef struct aecf_pool_bwd_args {
@@ -176,6 +187,7 @@ typedef struct aecf_pool_bwd_args {
      * (aecf_amd/dp.py: GradOverlap).  stage_events are not recorded in this order of stages.
      * NULL = off. */
     void* param_grads_event;
+    const void* saved_o_lo;      /* AECF_HILO_GRADS: the forward's low part of saved_o, else NULL (ABI v8) */
 } aecf_pool_bwd_args;
 
 #define AECF_FWD_STAGES 4   /* prep, gate, vproj, outproj */
@@ -197,6 +209,8 @@ size_t aecf_pool_bwd_workspace_bytes(const aecf_pool_desc* d);
 int aecf_pool_wants_saved_v(const aecf_pool_desc* d);
 /* workspace bytes of a call with AECF_PRECISE set (backward == 0: forward) */
 size_t aecf_pool_precise_workspace_bytes(const aecf_pool_desc* d, int backward);
+/* backward workspace bytes of a call with AECF_HILO_GRADS set; 0 = the flag is not built for this description */
+size_t aecf_pool_hilo_bwd_workspace_bytes(const aecf_pool_desc* d);
 /* bytes of the optional parameter-preparation buffer shared by forward and backward (saved_prep) */
 size_t aecf_pool_prep_bytes(const aecf_pool_desc* d);
 

@@ -131,6 +131,49 @@ def test_full_size_bf16(name):
         assert e < 3e-3, (k, e)
 
 
+def test_full_size_bf16_parameters_c2():
+    """The BENCHMARKED combination (only checked at B <= 256 before): bf16 activations AND bf16 parameters at the
+    full headline batch -- the library rounds its float32 batch sums once into bf16 gradients.  Per-sample outputs bit-equal
+    to the float32-master run (the kernels see the same bf16 weights), gradients within the bf16-stored bounds of the oracle
+    on a chunk, run-to-run determinism, exact linearity in dy, additivity over the batch within two roundings."""
+    from oracle import aecf_oracle as O
+    from tests.helpers import BF16_BOUNDS
+    dt = torch.bfloat16
+    pool, query, x, dy, U, (B, M, E, H, chunk) = _setup("c2", dt, param_dtype=dt)
+    full = _run(pool, query, x, dy, U, dt)
+    for k in ("dw_in", "db_in", "dw_out", "db_out", "dq"):
+        assert full[k].dtype == dt, k
+    master_pool, master_q, *_ = _setup("c2", dt, param_dtype=torch.float32)
+    master = _run(master_pool, master_q, x, dy, U, dt)
+    for k in ("y", "w", "mw", "ent", "rate", "dx"):
+        assert torch.equal(master[k], full[k]), k
+    for k in ("dw_in", "db_in", "dw_out", "db_out", "dq"):          # the same float32 sums, rounded once
+        assert torch.equal(master[k].to(dt), full[k]), k
+    again = _run(pool, query, x, dy, U, dt)
+    for k in ("y", "dx", "dw_in", "db_in", "dw_out", "db_out", "dq"):
+        assert torch.equal(again[k], full[k]), k
+    twice = _run(pool, query, x, dy * 2, U, dt)
+    for k in ("dx", "dw_in", "dw_out", "db_in", "db_out", "dq"):
+        assert torch.equal(twice[k], full[k] * 2), k
+    h = B // 2
+    lo = _run(pool, query, x[:h], dy[:h], U[:h], dt)
+    hi = _run(pool, query, x[h:], dy[h:], U[h:], dt)
+    for k in ("dw_in", "dw_out", "db_in", "db_out", "dq"):
+        assert rel_err(lo[k].float() + hi[k].float(), full[k].float()) < 8e-3, k       # three bf16 roundings
+    a = pool.attention
+    c = lambda t_: t_.detach().float().cpu()
+    xs = x[:chunk].float()
+    qe = c(query).expand(chunk, -1, -1)
+    f = O.mha_forward(qe, xs, xs, c(a.in_proj_weight), c(a.in_proj_bias), c(a.out_proj.weight), c(a.out_proj.bias), H)
+    b = O.mha_backward(qe, xs, xs, c(a.in_proj_weight), c(a.in_proj_bias), c(a.out_proj.weight), H, f,
+                       dy[:chunk].float(), None)
+    ch = _run(pool, query, x[:chunk], dy[:chunk], U[:chunk], dt)
+    errs = {k: rel_err(c(ch[k]), b[k]) for k in ("dw_in", "db_in", "dw_out", "db_out")}
+    errs["dquery"] = rel_err(c(ch["dq"]), b["dquery"].sum(0, keepdim=True))
+    for k, e in errs.items():
+        assert e < BF16_BOUNDS[k], (k, e)
+
+
 def test_full_size_fp32_c2_chunk():
     """fp32 kernels at d=512 / 8 heads / M=3 against the oracle at 1e-5 (B limited by the oracle, not the kernel)."""
     from oracle import aecf_oracle as O
