@@ -1192,6 +1192,25 @@ __global__ __launch_bounds__(512, 2) void dsu_slab_kernel(BwdGArgs p, float* __r
         // (the slab's NDMA = 2 M pieces go out one per (head group, modality) pass of phase 1 below: a copy instruction costs its
         //  wave 100-200 issue cycles -- seven in a row at the top of the step were ~1000 cycles in front of the first MFMA)
         if (more) load_stats(o0 + 16, pmv_n, dwb_n);
+#ifdef AECF_ABL_DSU_WSTREAM
+        // TIMING-ONLY emulation of a fused dout -> dscore kernel ("do never exists in HBM"): the block would
+        // form do_h = dy W_o^T[:, its 256 columns] itself, i.e. stream its 256 KB slice of W_o^T through LDS every 16-sample
+        // step (the register file holds W_v^T).  Here AECF_ABL_DSU_WSTREAM 1 KB pieces per wave and step (32 = the full slice)
+        // are copied from the L2-resident weights into a scratch slot and never read: the copies' cost alone, without the 32
+        // extra MFMAs per wave and step the product itself would add.
+        {
+            const char* wsrc_b = reinterpret_cast<const char*>(p.wvt) + (size_t)w * 32768;
+#pragma unroll 4
+            for (int i = 0; i < AECF_ABL_DSU_WSTREAM; ++i) {
+                const unsigned int voff = (unsigned)(i * 1024 + lane * 16);
+                const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(reinterpret_cast<char*>(dsw) + 8 * 2 * 4 * 72 * 2 + w * 1024);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(wsrc_b), "s"(dst) : "memory", "m0");
+#pragma clang diagnostic pop
+            }
+        }
+#endif
         // ---- phase 1: P_h by MFMA, dot with this lane's x values, partial dots to LDS
         const char* tb = db + dcur * DT;
         const char* xs = xb + cur * XT;
@@ -1324,7 +1343,7 @@ __global__ __launch_bounds__(512, 2) void dsu_slab_kernel(BwdGArgs p, float* __r
 template <int M_>
 int launch_dsu_slab(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     constexpr int XT = 8 * 16 * M_ * 128;
-    const size_t smem = (size_t)2 * XT + 256 + (size_t)3 * 16 * 512 + (size_t)2 * 8 * 4 * 16 * 4 * 4 + (size_t)8 * 2 * 4 * 72 * 2;
+    const size_t smem = (size_t)2 * XT + 256 + (size_t)3 * 16 * 512 + (size_t)2 * 8 * 4 * 16 * 4 * 4 + (size_t)8 * 2 * 4 * 72 * 2 + 8192 /* (ablation scratch) */;
     const int groups = 2;
     const int64_t chunks = 256 / groups;
     int64_t rpb = (a.B + chunks - 1) / chunks;
