@@ -82,7 +82,10 @@ BwdWs bwd_layout(const aecf_pool_desc* d, bool hilo = false) {
     w.splits = S;
     w.rows_per_split = rps;
     {   // u = ds^T x: [16, E] per batch split, ~512 blocks of 8 waves (2 per CU)
-        int Su = 512;
+#ifndef AECF_USU
+#define AECF_USU 512
+#endif
+        int Su = AECF_USU;
         const int64_t max_su = (int64_t)((B + 63) / 64);
         if (Su > max_su) Su = (int)max_su;
         if (Su < 1) Su = 1;

@@ -410,6 +410,7 @@ void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s) {
     }
     const bool do_main = a.parts != 2, do_u = a.parts != 1;
     if (dtype == 0 && do_main) launch_gemm_tn_tr(a, s);
+    if (dtype == 0 && do_u && u_mfma_supported(a) && !env_no_ws()) { launch_u_mfma(a, s); return; }
     AECF_DISPATCH_M(a.M, {
         if (dtype == 0) { if (do_u) launch_u<BF16, M_>(a, s); }
         else { if (do_main) launch_wj<F32, M_, true>(a, s); if (do_u) launch_u<F32, M_>(a, s); }

@@ -632,6 +632,143 @@ void launch_one(const GemmTnArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------
+// u[h][k] = sum_{b,m} ds[b,h,m] x[b,m,k]  as a streaming kernel on the matrix pipe (round 4; bf16, H <= 8): the key-side batch
+// reduction of the shapes whose score gradient does not form it (d = 768 / 1024).  u_stream_kernel did it with float32 FMAs
+// on register-resident rows (8 H M FMAs per 16 bytes of x: 43 us for the 134 MB of the configs[4] shard, 3.1 TB/s); here the
+// rows are the K index of an MFMA whose A operand is read TRANSPOSED out of an LDS tile (the u phase of dsu_ws_kernel as
+// its own kernel): u^T[k, slot] += x^T[k, (b,m)] dsop[(b,m), slot], slots 0-7 = bf16 hi of ds per head, 8-15 = lo, added
+// at the end.  Block = 4 waves, a [32 flat rows][128 columns] tile per step by LDS-DMA, three buffers (two tiles in
+// flight), one barrier per step; grid = (E / 128 column tiles) x (batch splits): many small blocks per CU, so the kernel is
+// bound by the row stream alone.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void u_mfma_kernel(GemmTnArgs p) {
+    using X = Tr<BF16>;
+    constexpr int NT = 64 * NW, ROWB = 64 * NW, CPR = 4 * NW;      // threads, tile row bytes (32 columns per wave), chunks per row
+    constexpr int TB = 32 * ROWB;                                  // bytes of one x tile
+    constexpr int DSS = 40;                                        // ds operand row: 32 K slots + 8 (rows 5 x 16 B apart)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xt = smem;                                               // [3][32][ROWB]
+    unsigned short (*dsop)[16 * DSS] = reinterpret_cast<unsigned short (*)[16 * DSS]>(smem + 3 * TB);   // [2][16][DSS]
+    const int E = p.E, H = p.H, M = p.M;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const int k0 = blockIdx.x * (32 * NW);
+    const int split = blockIdx.y;
+    const int64_t fbeg = (int64_t)split * p.u_rows_per_split * M;   // flat (b, m) rows of this split
+    int64_t fend = fbeg + p.u_rows_per_split * M;
+    if (fend > p.B * M) fend = p.B * M;
+    if (fbeg >= fend) return;
+    const char* xsrc = reinterpret_cast<const char*>(p.rhs) + (int64_t)k0 * 2;
+    const unsigned int ldx = (unsigned)E * 2u;
+
+    for (int i = threadIdx.x; i < 2 * 16 * DSS / 2; i += NT) reinterpret_cast<unsigned int*>(smem + 3 * TB)[i] = 0u;   // (padding stays 0)
+    // tile image: 256-byte rows, chunk ch of row r at ch ^ key(r), key = ((r & 3) << 2) | ((r >> 2) & 3)  (T10, image (b)):
+    // conflict-free for the transposed reads below; the DMA destination is lane-linear, the permutation goes on the source
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    auto issue_tile = [&](int64_t f0, int buf) {
+        const int nv = (int)((fend - f0) < 32 ? (fend - f0) : 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = threadIdx.x + NT * i;
+            const int row = c / CPR, pch = c - row * CPR;
+            const int key = ((row & 3) << 2) | ((row >> 2) & 3);     // (on the chunk's low 4 bits: inside its 256-byte segment)
+            const int rowc = row < nv ? row : nv - 1;
+            const unsigned int voff = (unsigned)rowc * ldx + (unsigned)((pch ^ key) << 4);
+            const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(xt + buf * TB + (64 * w + NT * i) * 16);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(xsrc + f0 * (int64_t)ldx), "s"(dst)
+                         : "memory", "m0");
+        }
+    };
+#pragma clang diagnostic pop
+    // ds staging role: flat row fr = t >> 3 of the step, head t & 7
+    const int fr = (threadIdx.x >> 3) & 31, hh = threadIdx.x & 7;     // (threads >= 256 repeat the first 256: same values, same slots)
+    float dsv = 0.f;
+    auto load_ds = [&](int64_t f0) {
+        const int64_t f = f0 + fr;
+        const int64_t fc = f < fend ? f : fend - 1;
+        const int64_t b = fc / M;
+        const int m = (int)(fc - b * M);
+        const float* src = p.dsbuf + (b * H + (hh < H ? hh : 0)) * M + m;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(dsv) : "v"(src) : "memory");
+    };
+    // transposed-read addresses (constant): K slot 8 lg + 4 hi + q = tile row, columns 32 w + 16 ct + 4 pp .. + 3
+    const int q = r16 >> 2, pp = r16 & 3;
+    int ta[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int row = 8 * lg + 4 * hi + q;
+            const int key = ((row & 3) << 2) | ((row >> 2) & 3);
+            const int ch = 4 * w + 2 * ct + (pp >> 1);
+            ta[ct][hi] = ROWB * row + ((ch ^ key) << 4) + 8 * (pp & 1);
+        }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+    issue_tile(fbeg, 0);
+    load_ds(fbeg);
+    if (fbeg + 32 < fend) issue_tile(fbeg + 32, 1);
+    int buf = 0, step = 0;
+    for (int64_t f0 = fbeg; f0 < fend; f0 += 32, buf = buf == 2 ? 0 : buf + 1, ++step) {
+        // tile(step) and ds(step) landed: behind them only the 2 copies of tile(step + 1) may still fly
+        if (f0 + 32 < fend) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(dsv));
+        {
+            const bool on = f0 + fr < fend && hh < H;
+            const float d = on ? dsv : 0.f;
+            const unsigned short hi = X::from_f32(d);
+            if (threadIdx.x < 256) {
+                dsop[step & 1][hh * DSS + fr] = hi;
+                dsop[step & 1][(8 + hh) * DSS + fr] = X::from_f32(d - X::to_f32(hi));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // tile + operand of this step visible; the previous step's reads done
+        if (f0 + 32 < fend) load_ds(f0 + 32);
+        if (f0 + 64 < fend) issue_tile(f0 + 64, buf == 0 ? 2 : buf - 1);
+        const u32x4 bop = *reinterpret_cast<const u32x4*>(&dsop[step & 1][r16 * DSS + 8 * lg]);
+        const char* tile = xt + buf * TB;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const u32x4 af = tr_frag(tile, ta[ct][0], ta[ct][1]);
+            acc[ct] = X::mma(af, bop, acc[ct]);
+        }
+    }
+    // slots r16 (hi) and r16 + 8 (lo) of a head meet; lane (lg, r16 = head) stores columns k0 + 32 w + 16 ct + 4 lg .. + 3
+    float* u = p.u + (int64_t)split * H * E;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        f32x4 v = acc[ct];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], 8, 64);
+        if (r16 < H && r16 < 8) *reinterpret_cast<f32x4*>(u + (int64_t)r16 * E + k0 + 32 * w + 16 * ct + 4 * lg) = v;
+    }
+}
+
+#ifndef AECF_UNW
+#define AECF_UNW 0
+#endif
+bool u_mfma_supported(const GemmTnArgs& a) { return a.H <= 8 && a.E % 128 == 0 && a.M >= 1 && a.u_splits > 0; }
+
+// block width: 32 columns per wave; the widest block whose columns tile E (each x row is then read in the fewest pieces)
+void launch_u_mfma(const GemmTnArgs& a, hipStream_t s) {
+    int nw = AECF_UNW;
+    if (nw == 0) nw = a.E % 512 == 0 ? 16 : (a.E % 256 == 0 ? 8 : 4);
+    dim3 grid((unsigned)(a.E / (32 * nw)), (unsigned)a.u_splits);
+    const size_t smem = (size_t)3 * 32 * 64 * nw + (size_t)2 * 16 * 40 * 2;
+    if (nw == 16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(u_mfma_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        u_mfma_kernel<16><<<grid, dim3(1024), smem, s>>>(a);
+    } else if (nw == 8) {
+        u_mfma_kernel<8><<<grid, dim3(512), smem, s>>>(a);
+    } else {
+        u_mfma_kernel<4><<<grid, dim3(256), smem, s>>>(a);
+    }
+}
+
 // head slots a block needs = the most heads any aligned 128-row window of the E output rows touches
 static int max_slots_128(int E, int hd) {
     int mx = 1;

@@ -169,6 +169,8 @@ struct GemmTnArgs {
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b64_tr_b16 form (main product only)
+bool u_mfma_supported(const GemmTnArgs& a);                    // u = ds^T x on the matrix pipe (bf16, H <= 8, E % 128 == 0)
+void launch_u_mfma(const GemmTnArgs& a, hipStream_t s);
 
 // dst[g][i] = sum_s src[g][s*n[g] + i] for each of N segments, one launch
 struct ReduceSegs {
