@@ -582,6 +582,33 @@ def main():
         st.disarm()
         torch.cuda.synchronize()
         st.collect()
+    # N > 1, weak scaling (what the driver's one run per N measures): the STRONG-scaling point of the same N rides along in the
+    # same line (field "strong_scaling"), after the timed region and the stage pass -- the config's global batch sharded over the
+    # ranks, same step, same collective -- so that one lease of a multi-GPU node yields both curves
+    strong = None
+    if world > 1 and args.scaling == "weak" and nce is None and graph is None:
+        import torch.distributed as dist
+        lo_s, hi_s = dp.shard_bounds(Bc, rank, world)
+        bs = hi_s - lo_s
+        xs = x.detach()[:bs].clone().requires_grad_(True)
+        dys = dy[:bs]
+        sgen = torch.Generator(device=device).manual_seed(4321)
+
+        def strong_step():
+            us = torch.rand(Bc, 1, M, device=device, dtype=torch.float32, generator=sgen)[lo_s:hi_s]
+            return step(pool, query, xs, dys, params, True, us, overlap)
+        for _ in range(max(5, args.warmup)):
+            strong_step()
+        barrier()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            strong_step()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - ts0], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sec_s = float(tt[0].item()) / args.steps
+        strong = {"value": Bc / sec_s, "unit": "samples/s", "ms_per_step": sec_s * 1e3, "global_batch": Bc,
+                  "per_gpu_batch": bs, "scaling": "strong", "steps": args.steps}
     nce_ms = None
     if nce is not None:                  # the two C-ABI calls of the loss side, HIP events on the launch stream
         from aecf_amd import _lib
@@ -687,6 +714,9 @@ def main():
             "stage_pass": {"steps": STAGE_PASS_STEPS, "when": "after the timed region", "stat": "median"},
             "graph_replay": graph is not None,
             "cpu_baseline": cb,
+            "strong_scaling": strong,
+            "collective_library": None if world == 1 else (
+                f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())}" if backend == "nccl" else backend),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -203,6 +203,25 @@ def test_bench_gpus2_launches_two_ranks():
 
 
 @pytest.mark.timeout(600)
+def test_bench_weak_scaling_line_carries_the_strong_point():
+    """The driver runs ONE `bench.py --gpus N` per N (weak scaling): the same line also carries the strong-scaling point of
+    that N and names the collective library, so one lease of a multi-GPU node yields both curves."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if torch.cuda.device_count() < 2:
+        env["AECF_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "5",
+                        "--warmup", "2"], env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 2 * 4096
+    st = line["strong_scaling"]
+    assert st["scaling"] == "strong" and st["global_batch"] == 4096 and st["per_gpu_batch"] == 2048 and st["value"] > 0
+    assert line["collective_library"]
+
+
+@pytest.mark.timeout(600)
 def test_trainer_two_ranks_learns_and_toggles():
     """The runnable trainer (aecf_amd/train_xray.py; ref xrays/train_xrays_example.py:312-377): 2 ranks, curriculum + missing-
     modality training switched on mid-run, loss goes down, validation mAP well above chance, toggled epochs report it."""
