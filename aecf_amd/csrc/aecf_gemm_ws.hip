@@ -43,6 +43,16 @@ namespace {
 
 enum { WS_PLAIN = 0, WS_VPROJ = 1, WS_VFLAT = 2 };
 
+#ifndef AECF_WS_PLAIN_BUFS
+#define AECF_WS_PLAIN_BUFS 2
+#endif
+// LDS tiles of gemm_ws_kernel.  -DAECF_WS_PLAIN_BUFS=3 gives the plain form a third tile (copy two steps ahead); measured
+// neutral at C2 (38 us either way, profiles/r04_c2_plain_ablation.txt: copy, stores and MFMA + operand reads each take ~19 us
+// on their own and already overlap), so the default stays at two
+constexpr int ws_plain_bufs(int mode, int kt) {
+    return (mode == WS_PLAIN && AECF_WS_PLAIN_BUFS == 3 && 3 * 32 * 64 * kt <= 150 * 1024) ? 3 : 2;
+}
+
 // copy NROWS rows (K bf16 each) to an LDS tile; row r's physical chunk p holds logical chunk p ^ key(r),
 // key(r) = (r / KEYDIV) & 15.  Rows >= rows_valid re-read the last valid row (their outputs are never stored).
 template <int KT, int NROWS, int KEYDIV>
@@ -149,6 +159,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     constexpr int SROWS = 16 * RT;                                // A rows per step
     constexpr int OROWS = PL ? 32 : 16;             // output rows (PLAIN) / samples (VPROJ) per step
     constexpr int TILE = SROWS * ROWB;
+    constexpr int NBUF = ws_plain_bufs(MODE, KT);                 // PLAIN: three tiles, the copy runs TWO steps ahead
+    constexpr int NI_DMA = SROWS * 4 * KT / 512;                  // LDS-DMA wave-instructions of one tile per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
@@ -177,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
     };
 
     issue(o_beg, 0);                                              // the first tile flies while the weights load
+    if (NBUF == 3 && o_beg + OROWS < o_end) issue(o_beg + OROWS, 1);
 
     // side job of the launch's first block (out-projection of a training-mode forward): the entropy regulariser's final sum
     // over the statistics kernel's per-block partials (ref aecf/AECFLayer.py:309-314: mean, clamp at 0) -- one wave, fixed order
@@ -267,12 +280,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
         else asm volatile("" : "+v"(pm[m]));
     }
     int cur = 0;
-    for (int64_t o0 = o_beg; o0 < o_end; o0 += OROWS, cur ^= 1) {
+    for (int64_t o0 = o_beg; o0 < o_end; o0 += OROWS, cur = (cur + 1 == NBUF ? 0 : cur + 1)) {
         __builtin_amdgcn_s_barrier();                              // tile visible to all waves; other buffer free
         // GATE: the next tile's copy is issued among the first MFMAs of the step (below), not here: at the top its six
         // wave-instructions and their address arithmetic sit in front of the score phase, which every wave of the block
         // then waits for at the second barrier (value projection 130 -> 121 us at C2)
-        if (!GATE && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);
+        // PLAIN (three buffers): the copy of step s + 2 goes into the tile step s - 1 read (every wave is past it: barrier);
+        // a step of 64 MFMAs per wave is shorter than one HBM round trip under load, so one step of lead left the wait at the
+        // end of every step exposed
+        const bool two_ahead = NBUF == 3 && o0 + 2 * OROWS < o_end;
+#ifdef AECF_ABL_PL_NODMA
+        if (MODE != WS_PLAIN) { if (!GATE && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1); }
+#else
+        if (NBUF == 3) { if (two_ahead) issue(o0 + 2 * OROWS, cur >= 1 ? cur - 1 : 2); }
+        else if (!GATE && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);
+#endif
         if (o0 + OROWS < o_end) load_probs(o0 + OROWS, pm_next);
 
         if (GATE) {
@@ -354,6 +376,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
             if (GATE && i == NIT / 8 && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);   // 7/8 of the MFMA phase to land in
             const int ks = PL ? i / RT : i % KT;
             const int t = PL ? i % RT : 0;
+#ifdef AECF_ABL_PL_NOMMA
+            if (MODE == WS_PLAIN) { if (i % 16 == 0) for (int c = 0; c < CT; ++c) acc[t][c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[t][c]);
+                                    else asm volatile("" :: "v"(xf[i % (PF + 1)])); } else
+#endif
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[t][c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[t][c]);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
@@ -375,7 +401,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
             }
         }
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tile (and its probabilities) landed
+        // next tile (and its probabilities) landed.  Three buffers: only the NI_DMA copies of step s + 2 -- the youngest loads --
+        // may stay in flight (loads return in order, so a count <= NI_DMA cannot include a copy of step s + 1; the previous
+        // step's stores are older than those copies and are retired here as well, whatever order they complete in)
+        if (two_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI_DMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float pm_now[NPM];                                         // (the weights of THIS step: pm is refilled below)
 #pragma unroll
         for (int m = 0; m < NPM; ++m) pm_now[m] = pm[m];
@@ -400,6 +430,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[t][c][r] + bias[4 * c + r];
                 if (!VF) {
+#ifdef AECF_ABL_PL_NOSTORE
+                    for (int j = 0; j < NV; ++j) asm volatile("" :: "v"(v[j]));
+                    if (false)
+#endif
                     if (row < o_end) {
                         if (p.out_f32) store_cols_f32<CT>(reinterpret_cast<float*>(p.c) + row * N + ncol0 + NV * lg, v);
                         else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + NV * lg, v);
@@ -1698,7 +1732,7 @@ void launch_ws(const GemmNtArgs& a, hipStream_t s) {
     constexpr int CT = KT <= 16 ? 2 : 1;                           // 32 columns per wave up to K = 512, 16 beyond
     constexpr int RT = MODE != WS_VPROJ ? 2 : M_;
     constexpr int OROWS = MODE != WS_VPROJ ? 32 : 16;
-    size_t smem = (size_t)2 * 16 * RT * 2 * K;
+    size_t smem = (size_t)ws_plain_bufs(MODE, KT) * 16 * RT * 2 * K;
     const int groups = a.N / (128 * CT);
     // about one block per CU (256): chunks of whole steps
     int64_t chunks = 256 / groups;
