@@ -137,6 +137,11 @@ _SYMBOLS = [
     ("aecf_route_build", c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_rows_gather", c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     ("aecf_rows_select", c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    ("aecf_front_pair", c_int, [c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("aecf_adamw_step", c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                c_float, c_float, c_float, c_void_p]),
+    ("aecf_rows_split", c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_l2norm_forward", c_int, [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_l2norm_backward", c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_nce_workspace_bytes", c_size_t, [c_int64, c_int64, c_int32, c_int32]),

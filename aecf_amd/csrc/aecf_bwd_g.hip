@@ -72,7 +72,11 @@ __global__ __launch_bounds__(G_THREADS) void bwd_g_kernel(BwdGArgs p) {
     DirectStage<G_SAMPLES, G_THREADS> sb;
     int pending_h = -1;                                          // DA: head whose slots wait to be folded into da
 
-    for (int kb = 0; kb < nkb; ++kb) {
+    // DX with a 2-D grid (few samples: launch_one below): one 128-row block of E per blockIdx.y -- the passes over kb share
+    // nothing but the per-sample scalars loaded above
+    const int kb_begin = (DX && gridDim.y > 1) ? (int)blockIdx.y : 0;
+    const int kb_end = (DX && gridDim.y > 1) ? kb_begin + 1 : nkb;
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
         const int rows_k = (E - kb * 128) >= 128 ? 128 : (E - kb * 128);
         const bool wave_on = 64 * rh < rows_k;                   // this wave's 64 E-rows exist
         const int krow = kb * 128 + 64 * rh + 4 * lg;            // E index of accumulator row (rt, r): krow + 16 rt + r
@@ -231,6 +235,7 @@ static void launch_one(const BwdGArgs& a, hipStream_t s) {
     const size_t floats = DX ? (2 * G_SAMPLES * HM + (size_t)a.H * 128) : (G_SAMPLES * HM + 2 * 2 * G_SAMPLES * (size_t)a.M);
     const size_t smem = (size_t)(128 + G_SAMPLES) * TILE_ROW_BYTES + floats * sizeof(float);
     dim3 grid((unsigned)((a.B + G_SAMPLES - 1) / G_SAMPLES)), block(G_THREADS);
+    if (DX && grid.x < 64) grid.y = (unsigned)((a.E + 127) / 128);       // a few hundred samples: spread the E blocks too
     auto kern = bwd_g_kernel<T, M_, DX>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -867,10 +867,44 @@ int aecf_rows_gather(int32_t njobs, const void* const* src, const int64_t* src_p
 int aecf_rows_select(int64_t rows, int64_t row_bytes, const int32_t* route, const int32_t* slot, const void* const* src,
                      const int64_t* src_pitch, void* dst, int64_t dst_pitch, void* stream) {
     if (rows <= 0 || row_bytes <= 0 || row_bytes % 2 != 0 || dst_pitch % 2 != 0) return AECF_ERR_BAD_DIMS;
-    if (!route || !slot || !src || !src_pitch || !dst) return AECF_ERR_NULL_POINTER;
+    if (!route || !src || !src_pitch || !dst) return AECF_ERR_NULL_POINTER;          // slot may be NULL: identity
     for (int k = 0; k < 3; ++k)
         if (src_pitch[k] % 2 != 0) return AECF_ERR_BAD_DIMS;
     launch_rows_select(rows, row_bytes, route, slot, src, src_pitch, dst, dst_pitch, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_adamw_step(int32_t n, void* const* param, const void* const* grad, void* const* exp_avg, void* const* exp_avg_sq,
+                    void* const* step, const int64_t* numel, void* ticket, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, void* stream) {
+    if (n <= 0) return AECF_ERR_BAD_DIMS;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step || !numel || !ticket) return AECF_ERR_NULL_POINTER;
+    for (int i = 0; i < n; ++i) {
+        if (numel[i] <= 0) return AECF_ERR_BAD_DIMS;
+        if (!param[i] || !grad[i] || !exp_avg[i] || !exp_avg_sq[i] || !step[i]) return AECF_ERR_NULL_POINTER;
+    }
+    launch_adamw_multi(n, (float* const*)param, (const float* const*)grad, (float* const*)exp_avg, (float* const*)exp_avg_sq,
+                       (float* const*)step, numel, (unsigned int*)ticket, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_rows_split(int64_t rows, int64_t row_bytes, const int32_t* route, const void* src, void* const* dst, void* stream) {
+    if (rows <= 0 || row_bytes <= 0 || row_bytes % 2 != 0) return AECF_ERR_BAD_DIMS;
+    if (!route || !src || !dst) return AECF_ERR_NULL_POINTER;
+    launch_rows_split(rows, row_bytes, route, src, dst, (hipStream_t)stream);
+    return launch_status();
+}
+
+int aecf_front_pair(int64_t rows, int32_t dim_a, int32_t dim_b, int32_t dtype, const void* feat_a, const void* feat_b,
+                    const float* uniforms, float missing_prob, const uint8_t* drop_a, const uint8_t* drop_b, void* out_a,
+                    void* out_b, uint8_t* present_a, uint8_t* present_b, int32_t* cls, void* stream) {
+    if (rows <= 0 || dim_a <= 0 || dim_b <= 0) return AECF_ERR_BAD_DIMS;
+    if (dtype != AECF_BF16 && dtype != AECF_F32) return AECF_ERR_UNSUPPORTED;
+    if (!feat_a || !feat_b || !out_a || !out_b || !present_a || !present_b || !cls) return AECF_ERR_NULL_POINTER;
+    if (uniforms && (drop_a || drop_b)) return AECF_ERR_BAD_DIMS;                      // one source of decisions
+    if (out_a == feat_a || out_b == feat_b) return AECF_ERR_UNSUPPORTED;               // (the row is read twice)
+    launch_front_pair(dtype, rows, dim_a, dim_b, feat_a, feat_b, uniforms, missing_prob, drop_a, drop_b, out_a, out_b,
+                      present_a, present_b, cls, (hipStream_t)stream);
     return launch_status();
 }
 

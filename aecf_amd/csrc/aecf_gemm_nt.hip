@@ -20,12 +20,15 @@
 
 namespace aecf {
 
-template <typename T, int M_, bool POOLED>
+// WT = 16 x 16 MFMA tiles per wave and dimension: 4 (block tile 128 x 128) or 1 (32 x 32: problems of a few hundred rows --
+// the example model's batch of 64 -- would otherwise run on one or two CUs, 26 us for a [64 x 256] . [256 x 256]^T in float32)
+template <typename T, int M_, bool POOLED, int WT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
     constexpr int NA = POOLED ? M_ : 1;          // A-side LDS tiles (one per modality when pooling)
-    constexpr int TILE = 128 * TILE_ROW_BYTES;   // 16 KB
+    constexpr int BT = 32 * WT, WTR = 16 * WT;   // block tile and wave tile edge
+    constexpr int TILE = BT * TILE_ROW_BYTES;    // 16 KB (WT = 4)
     constexpr int BK = TileK<T>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsA = smem;
@@ -34,11 +37,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     const int wr = w >> 1, wc = w & 1;
     unsigned int panel, coltile;
-    if (!xcd_tile(blockIdx.x, (unsigned)((p.R + 127) / 128), (unsigned)((p.N + 127) / 128), panel, coltile)) return;
-    const int64_t r0 = (int64_t)panel * 128;
-    const int n0 = coltile * 128;
-    const int rows_valid = (p.R - r0) >= 128 ? 128 : (int)(p.R - r0);
-    const int cols_valid = (p.N - n0) >= 128 ? 128 : (p.N - n0);
+    if (!xcd_tile(blockIdx.x, (unsigned)((p.R + BT - 1) / BT), (unsigned)((p.N + BT - 1) / BT), panel, coltile)) return;
+    const int64_t r0 = (int64_t)panel * BT;
+    const int n0 = coltile * BT;
+    const int rows_valid = (p.R - r0) >= BT ? BT : (int)(p.R - r0);
+    const int cols_valid = (p.N - n0) >= BT ? BT : (p.N - n0);
     const int K = p.K;
     const int nkt = K / BK;
 
@@ -48,11 +51,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     const int64_t ldw_bytes = (int64_t)K * X::BYTES;
 
     // wave-level column bookkeeping
-    const int nw0 = n0 + 64 * wc;
-    int nct = (p.N - nw0) >= 64 ? 4 : ((p.N - nw0) > 0 ? (p.N - nw0) / 16 : 0);
+    const int nw0 = n0 + WTR * wc;
+    int nct = (p.N - nw0) >= WTR ? WT : ((p.N - nw0) > 0 ? (p.N - nw0) / 16 : 0);
     int head[4];
     float pr[4][4][M_];
-    if (POOLED) {
+    if (POOLED && WT == 4) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             int h = (nw0 + 16 * ct) / p.hd;
@@ -69,44 +72,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         }
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[WT][WT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < WT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < WT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (!POOLED) {
         // LDS-DMA, two buffers, one barrier per K tile: barrier (tile kt landed, tile kt-1 consumed) -> issue kt+1 -> MFMAs of kt
-        dma_tile<128, 256>(a_src, lda_bytes, rows_valid, ldsA);
-        dma_tile<128, 256>(w_src, ldw_bytes, cols_valid, ldsB);
+        dma_tile<BT, 256>(a_src, lda_bytes, rows_valid, ldsA);
+        dma_tile<BT, 256>(w_src, ldw_bytes, cols_valid, ldsB);
         for (int kt = 0; kt < nkt; ++kt) {
             char* curA = ldsA + (kt & 1) * 2 * TILE;
             char* curB = ldsB + (kt & 1) * 2 * TILE;
             __syncthreads();
             if (kt + 1 < nkt) {
                 const int64_t koff = (int64_t)(kt + 1) * TILE_ROW_BYTES;
-                dma_tile<128, 256>(a_src + koff, lda_bytes, rows_valid, ldsA + ((kt + 1) & 1) * 2 * TILE);
-                dma_tile<128, 256>(w_src + koff, ldw_bytes, cols_valid, ldsB + ((kt + 1) & 1) * 2 * TILE);
+                dma_tile<BT, 256>(a_src + koff, lda_bytes, rows_valid, ldsA + ((kt + 1) & 1) * 2 * TILE);
+                dma_tile<BT, 256>(w_src + koff, ldw_bytes, cols_valid, ldsB + ((kt + 1) & 1) * 2 * TILE);
             }
-            tile_mma<T, 4, 4>(acc, curA, 64 * wr, curB, 64 * wc);
+            tile_mma<T, WT, WT>(acc, curA, WTR * wr, curB, WTR * wc);
         }
     }
     // ---------------- epilogue ----------------
     const elem* bias = reinterpret_cast<const elem*>(p.bias);
-    float bv[4];
+    float bv[WT];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < WT; ++ct) {
         const int n = nw0 + 16 * ct + r16;
         bv[ct] = (bias && ct < nct) ? X::to_f32(bias[n]) : 0.f;
     }
-    if (X::BYTES == 2 && !p.out_f32) {
+    if (X::BYTES == 2 && !p.out_f32 && WT == 4) {
         // accumulators -> LDS as a [128][128] bf16 image (256-byte rows), then full-row 16-byte stores
         __syncthreads();
         char* cl = smem;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < WT; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int ct = 0; ct < WT; ++ct) {
                 // lane r16 holds column c for rows 4*lg + 0..3; pair columns (c, c+1) across lanes r16 ^ 1
                 float v0 = acc[rt][ct][0] + bv[ct], v1 = acc[rt][ct][1] + bv[ct];
                 float v2 = acc[rt][ct][2] + bv[ct], v3 = acc[rt][ct][3] + bv[ct];
@@ -134,14 +137,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     } else {
         elem* c = reinterpret_cast<elem*>(p.c);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+        for (int ct = 0; ct < WT; ++ct) {
             if (ct < nct) {
                 const int n = nw0 + 16 * ct + r16;
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
+                for (int rt = 0; rt < WT; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int64_t row = r0 + 64 * wr + 16 * rt + 4 * lg + r;
+                        const int64_t row = r0 + WTR * wr + 16 * rt + 4 * lg + r;
                         if (row < p.R) {
                             if (p.out_f32) reinterpret_cast<float*>(p.c)[row * p.N + n] = acc[rt][ct][r] + bv[ct];
                             else c[row * p.N + n] = X::from_f32(acc[rt][ct][r] + bv[ct]);
@@ -152,12 +155,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     }
 }
 
-template <typename T, int M_, bool POOLED>
+template <typename T, int M_, bool POOLED, int WT = 4>
 static void launch_one(const GemmNtArgs& a, hipStream_t s) {
     constexpr int NA = POOLED ? M_ : 1;
-    const size_t smem = (size_t)(POOLED ? (NA + 1) : 4) * 128 * TILE_ROW_BYTES;
-    dim3 grid(xcd_grid((unsigned)((a.R + 127) / 128), (unsigned)((a.N + 127) / 128))), block(256);
-    auto kern = gemm_nt_kernel<T, M_, POOLED>;
+    constexpr int BT = 32 * WT;
+    const size_t smem = (size_t)(POOLED ? (NA + 1) : 4) * BT * TILE_ROW_BYTES;
+    dim3 grid(xcd_grid((unsigned)((a.R + BT - 1) / BT), (unsigned)((a.N + BT - 1) / BT))), block(256);
+    auto kern = gemm_nt_kernel<T, M_, POOLED, WT>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     kern<<<grid, block, smem, s>>>(a);
@@ -167,7 +171,10 @@ void launch_gemm_nt(int dtype, const GemmNtArgs& a_in, hipStream_t s) {
     GemmNtArgs a = a_in;
     if (dtype == 0 && !env_no_ws() && gemm_ws_supported(a)) { launch_gemm_ws(a, s); return; }   // aecf_gemm_ws.hip
     if (a.pooled & 1) { launch_vproj(dtype, a, s); return; }     // per-modality accumulators (aecf_vproj.hip)
-    if (dtype == 0) launch_one<BF16, 1, false>(a, s); else launch_one<F32, 1, false>(a, s);
+    // fewer than 64 block tiles of 128 x 128: 32 x 32 tiles instead (16 x the blocks, each 1/16 of the K loop's MFMAs)
+    const bool small = ((a.R + 127) / 128) * (int64_t)((a.N + 127) / 128) < 64;
+    if (dtype == 0) { if (small) launch_one<BF16, 1, false, 1>(a, s); else launch_one<BF16, 1, false>(a, s); }
+    else { if (small) launch_one<F32, 1, false, 1>(a, s); else launch_one<F32, 1, false>(a, s); }
 }
 
 }  // namespace aecf

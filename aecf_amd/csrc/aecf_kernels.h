@@ -260,6 +260,13 @@ void launch_route_build(int64_t rows, const uint8_t* pa, const uint8_t* pb, int3
                         int32_t* counts, hipStream_t s);
 void launch_rows_gather(int njobs, const void* const* src, const int64_t* src_pitch, const int32_t* const* index,
                         const int64_t* n, void* const* dst, const int64_t* dst_pitch, int64_t row_bytes, hipStream_t s);
+void launch_adamw_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, float* const* step,
+                        const int64_t* numel, unsigned int* ticket, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        hipStream_t s);
+void launch_rows_split(int64_t rows, int64_t row_bytes, const int32_t* route, const void* src, void* const* dst, hipStream_t s);
+void launch_front_pair(int dtype, int64_t rows, int dim_a, int dim_b, const void* feat_a, const void* feat_b, const float* uniforms,
+                       float missing_prob, const uint8_t* drop_a, const uint8_t* drop_b, void* out_a, void* out_b,
+                       uint8_t* present_a, uint8_t* present_b, int32_t* cls, hipStream_t s);
 void launch_rows_select(int64_t rows, int64_t row_bytes, const int32_t* route, const int32_t* slot, const void* const* src,
                         const int64_t* src_pitch, void* dst, int64_t dst_pitch, hipStream_t s);
 

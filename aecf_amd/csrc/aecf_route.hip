@@ -121,13 +121,132 @@ __global__ __launch_bounds__(256) void rows_select_kernel(SelectArgs a) {
     if (c == 0) s = a.src[0]; else if (c == 1) s = a.src[1]; else if (c == 2) s = a.src[2];
     if (s) {
         const int64_t p = c == 0 ? a.src_pitch[0] : (c == 1 ? a.src_pitch[1] : a.src_pitch[2]);
-        copy_row(s + (int64_t)a.slot[r] * p, d, a.row_bytes, lane);
+        copy_row(s + (a.slot ? (int64_t)a.slot[r] : r) * p, d, a.row_bytes, lane);
     } else {
         zero_row(d, a.row_bytes, lane);
     }
 }
 
+// dst_c[r] = (route[r] == c) ? src[r] : 0 for c = 0..2: the backward of rows_select with identity slots (static routing: every
+// branch keeps all rows, a row's gradient goes to the branch that owned it), one launch for the three branches
+struct SplitArgs {
+    const char* src;
+    char* dst[3];
+    const int32_t* route;
+    int64_t row_bytes, rows;
+};
+__global__ __launch_bounds__(256) void rows_split_kernel(SplitArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave_id();
+    if (r >= a.rows) return;
+    const int lane = lane_id();
+    const int c = a.route[r];
+    const char* s = a.src + r * a.row_bytes;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!a.dst[k]) continue;
+        char* d = a.dst[k] + r * a.row_bytes;
+        if (c == k) copy_row(s, d, a.row_bytes, lane); else zero_row(d, a.row_bytes, lane);
+    }
+}
+
+// Both modality front-ends, the missing-modality decisions and the row classes of one batch in ONE launch (static routing:
+// ref xrays/train_xrays_example.py:156-177 draws, :173-176 zeroing, :202-207 presence and the three masks).  One wave per row.
+//   decisions: from uniforms [3, rows] (modality a dropped if u0 < p, b if u1 < p, a row that would lose both keeps a when
+//   u2 > 0.5 else b -- AECFModel.draw_missing's rule) or from the caller's drop vectors, or none;
+//   present_x = not dropped and ||row|| > 1e-6 (float32 sum of squares; false for NaN rows);
+//   out_x = row if present_x else zeros;  cls = 0 both, 1 only a, 2 only b, 3 neither.
+struct FrontPairArgs {
+    const void* feat[2];
+    void* out[2];
+    uint8_t* present[2];
+    const uint8_t* drop[2];
+    const float* uniforms;
+    int32_t* cls;
+    int64_t rows;
+    int dim[2];
+    float missing_prob;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void front_pair_kernel(FrontPairArgs a) {
+    using X = Tr<T>;
+    typedef typename X::elem elem;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave_id();
+    if (r >= a.rows) return;
+    const int lane = lane_id();
+    bool dropped[2] = {false, false};
+    if (a.uniforms) {
+        const float u0 = a.uniforms[r], u1 = a.uniforms[a.rows + r], u2 = a.uniforms[2 * a.rows + r];
+        const bool da = u0 < a.missing_prob, db = u1 < a.missing_prob, clash = da && db, keep_a = u2 > 0.5f;
+        dropped[0] = da && !(clash && keep_a);
+        dropped[1] = db && !(clash && !keep_a);
+    } else {
+        dropped[0] = a.drop[0] && a.drop[0][r] != 0;
+        dropped[1] = a.drop[1] && a.drop[1][r] != 0;
+    }
+    bool here[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int dim = a.dim[k];
+        const elem* src = reinterpret_cast<const elem*>(a.feat[k]) + r * dim;
+        elem* dst = reinterpret_cast<elem*>(a.out[k]) + r * dim;
+        const bool vec = (dim % X::EPL == 0) && ((reinterpret_cast<uintptr_t>(a.feat[k]) | reinterpret_cast<uintptr_t>(a.out[k])) % 16 == 0);
+        float ss = 0.f;
+        if (!dropped[k]) {
+            if (vec) {
+                for (int c = lane * X::EPL; c < dim; c += 64 * X::EPL) {
+                    float f[X::EPL];
+                    X::unpack(X::load(src + c), f);
+#pragma unroll
+                    for (int e = 0; e < X::EPL; ++e) ss = fmaf(f[e], f[e], ss);
+                }
+            } else {
+                for (int c = lane; c < dim; c += 64) { const float f = X::to_f32(src[c]); ss = fmaf(f, f, ss); }
+            }
+        }
+        ss = reduce_wave(ss);
+        here[k] = !dropped[k] && sqrtf(ss) > 1e-6f;
+        if (vec) {
+            for (int c = lane * X::EPL; c < dim; c += 64 * X::EPL)
+                *reinterpret_cast<typename X::frag*>(dst + c) = here[k] ? X::load(src + c) : X::zero();
+        } else {
+            for (int c = lane; c < dim; c += 64) dst[c] = here[k] ? src[c] : X::from_f32(0.f);
+        }
+    }
+    if (lane == 0) {
+        a.present[0][r] = here[0] ? 1 : 0;
+        a.present[1][r] = here[1] ? 1 : 0;
+        a.cls[r] = here[0] ? (here[1] ? 0 : 1) : (here[1] ? 2 : 3);
+    }
+}
+
 }  // namespace
+
+void launch_rows_split(int64_t rows, int64_t row_bytes, const int32_t* route, const void* src, void* const* dst, hipStream_t s) {
+    SplitArgs a;
+    a.src = (const char*)src;
+    for (int k = 0; k < 3; ++k) a.dst[k] = (char*)dst[k];
+    a.route = route;
+    a.row_bytes = row_bytes;
+    a.rows = rows;
+    rows_split_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s>>>(a);
+}
+
+void launch_front_pair(int dtype, int64_t rows, int dim_a, int dim_b, const void* feat_a, const void* feat_b, const float* uniforms,
+                       float missing_prob, const uint8_t* drop_a, const uint8_t* drop_b, void* out_a, void* out_b,
+                       uint8_t* present_a, uint8_t* present_b, int32_t* cls, hipStream_t s) {
+    FrontPairArgs a;
+    a.feat[0] = feat_a; a.feat[1] = feat_b;
+    a.out[0] = out_a; a.out[1] = out_b;
+    a.present[0] = present_a; a.present[1] = present_b;
+    a.drop[0] = drop_a; a.drop[1] = drop_b;
+    a.uniforms = uniforms;
+    a.cls = cls;
+    a.rows = rows;
+    a.dim[0] = dim_a; a.dim[1] = dim_b;
+    a.missing_prob = missing_prob;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == 0) front_pair_kernel<BF16><<<grid, block, 0, s>>>(a); else front_pair_kernel<F32><<<grid, block, 0, s>>>(a);
+}
 
 void launch_route_build(int64_t rows, const uint8_t* pa, const uint8_t* pb, int32_t* route, int32_t* slot, int32_t* index,
                         int32_t* counts, hipStream_t s) {

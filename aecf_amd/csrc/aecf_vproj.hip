@@ -12,7 +12,9 @@
 
 namespace aecf {
 
-template <typename T, int M_>
+// CW = 16-column MFMA tiles per wave: 4 (block tile 64 x 128), or 1 (64 x 32) for a few hundred samples, which would otherwise
+// sit on one or two CUs (the example model's batch of 64: 26 us in float32)
+template <typename T, int M_, int CW>
 __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
     using X = Tr<T>;
     typedef typename X::elem elem;
@@ -21,20 +23,21 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsA = smem;
     char* ldsB = smem + M_ * ATILE;
-    float* prl = reinterpret_cast<float*>(ldsB + 128 * TILE_ROW_BYTES);     // probs [64][H][M]
+    constexpr int BC = 32 * CW, WC = 16 * CW;                               // columns per block / per wave
+    float* prl = reinterpret_cast<float*>(ldsB + BC * TILE_ROW_BYTES);      // probs [64][H][M]
 
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     const int wr = w >> 1, wc = w & 1;
     unsigned int panel, coltile;
-    if (!xcd_tile(blockIdx.x, (unsigned)((p.R + 63) / 64), (unsigned)((p.N + 127) / 128), panel, coltile)) return;
+    if (!xcd_tile(blockIdx.x, (unsigned)((p.R + 63) / 64), (unsigned)((p.N + BC - 1) / BC), panel, coltile)) return;
     const int64_t r0 = (int64_t)panel * 64;
-    const int n0 = coltile * 128;
+    const int n0 = coltile * BC;
     const int rows_valid = (p.R - r0) >= 64 ? 64 : (int)(p.R - r0);
-    const int cols_valid = (p.N - n0) >= 128 ? 128 : (p.N - n0);
+    const int cols_valid = (p.N - n0) >= BC ? BC : (p.N - n0);
     const int K = p.K, H = p.H, HM = p.H * M_;
     const int nkt = K / BK;
-    const int nw0 = n0 + 64 * wc;
-    const int nct = (p.N - nw0) >= 64 ? 4 : ((p.N - nw0) > 0 ? (p.N - nw0) / 16 : 0);
+    const int nw0 = n0 + WC * wc;
+    const int nct = (p.N - nw0) >= WC ? CW : ((p.N - nw0) > 0 ? (p.N - nw0) / 16 : 0);
 
     for (int i = threadIdx.x; i < 64 * HM; i += 256)
         prl[i] = (i / HM) < rows_valid ? p.probs[r0 * HM + i] : 0.f;
@@ -44,16 +47,16 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
     const int64_t lda_bytes = p.lda * X::BYTES;
     const int64_t ldw_bytes = (int64_t)K * X::BYTES;
 
-    f32x4 acc[M_][2][4];
+    f32x4 acc[M_][2][CW];
 #pragma unroll
     for (int m = 0; m < M_; ++m)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[m][rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < CW; ++ct) acc[m][rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     DirectStage<64, 256> sa[M_];
-    DirectStage<128, 256> sb;
+    DirectStage<BC, 256> sb;
 #pragma unroll
     for (int m = 0; m < M_; ++m) sa[m].load(a_src + (int64_t)m * K * X::BYTES, lda_bytes, rows_valid);
     sb.load(w_src, ldw_bytes, cols_valid);
@@ -73,16 +76,16 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
         if (nct > 0) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                typename X::frag b[4];
+                typename X::frag b[CW];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) b[ct] = lds_frag<T>(ldsB, 64 * wc + 16 * ct + r16, 4 * ks + lg);
+                for (int ct = 0; ct < CW; ++ct) b[ct] = lds_frag<T>(ldsB, WC * wc + 16 * ct + r16, 4 * ks + lg);
 #pragma unroll
                 for (int m = 0; m < M_; ++m)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
                         const typename X::frag a = lds_frag<T>(ldsA + m * ATILE, 32 * wr + 16 * rt + r16, 4 * ks + lg);
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) acc[m][rt][ct] = X::mma(a, b[ct], acc[m][rt][ct]);
+                        for (int ct = 0; ct < CW; ++ct) acc[m][rt][ct] = X::mma(a, b[ct], acc[m][rt][ct]);
                     }
             }
         }
@@ -90,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
 
     // ---------------- epilogue: weight the per-modality products, add the bias ----------------
     const elem* bias = reinterpret_cast<const elem*>(p.bias);
-    f32x4 o[2][4];
+    f32x4 o[2][CW];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < CW; ++ct) {
         const int n = nw0 + 16 * ct + r16;
         const float bv = (bias && ct < nct) ? X::to_f32(bias[n]) : 0.f;
         int h = (nw0 + 16 * ct) / p.hd;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
     }
     // ---- stores.  bf16: ONE LDS pass -- image [64 rows][1 + M slots][128 cols] (slot 0 = o, slot 1+m = V_m, the
     //      per-modality products W x_m + bias kept for the backward score gradient), then full-row 16-byte stores.
-    if (X::BYTES == 2 && !p.out_f32) {
+    if (X::BYTES == 2 && !p.out_f32 && CW == 4) {
         const int nslot = p.v_out ? M_ + 1 : 1;
         const int pitch = nslot * 256;
         __syncthreads();
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int ct = 0; ct < CW; ++ct) {
                 put(0, rt, ct, o[rt][ct][0], o[rt][ct][1], o[rt][ct][2], o[rt][ct][3]);
                 if (p.v_out) {
                     const int n = nw0 + 16 * ct + r16;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
         elem* c = reinterpret_cast<elem*>(p.c);
         elem* vo = reinterpret_cast<elem*>(p.v_out);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+        for (int ct = 0; ct < CW; ++ct) {
             if (ct < nct) {
                 const int n = nw0 + 16 * ct + r16;
                 const float bv = bias ? X::to_f32(bias[n]) : 0.f;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         const int64_t row = r0 + 32 * wr + 16 * rt + 4 * lg + r;
                         if (row < p.R) {
-                            if (X::BYTES == 2) reinterpret_cast<float*>(p.c)[row * p.N + n] = o[rt][ct][r];    // out_f32
+                            if (X::BYTES == 2 && p.out_f32) reinterpret_cast<float*>(p.c)[row * p.N + n] = o[rt][ct][r];
                             else c[row * p.N + n] = X::from_f32(o[rt][ct][r]);
                             if (vo) {
 #pragma unroll
@@ -177,21 +180,24 @@ __global__ __launch_bounds__(256, 2) void vproj_modal_kernel(GemmNtArgs p) {
     }
 }
 
-template <typename T, int M_>
+template <typename T, int M_, int CW>
 static void launch_one(const GemmNtArgs& a, hipStream_t s) {
-    size_t smem = (size_t)M_ * 64 * TILE_ROW_BYTES + (size_t)128 * TILE_ROW_BYTES + (size_t)64 * a.H * M_ * sizeof(float);
-    const size_t image = (size_t)64 * 256 * (a.v_out ? M_ + 1 : 1);     // the bf16 output image(s)
+    constexpr int BC = 32 * CW;
+    size_t smem = (size_t)M_ * 64 * TILE_ROW_BYTES + (size_t)BC * TILE_ROW_BYTES + (size_t)64 * a.H * M_ * sizeof(float);
+    const size_t image = CW == 4 ? (size_t)64 * 256 * (a.v_out ? M_ + 1 : 1) : 0;     // the bf16 output image(s)
     if (smem < image) smem = image;
-    dim3 grid(xcd_grid((unsigned)((a.R + 63) / 64), (unsigned)((a.N + 127) / 128))), block(256);
-    auto kern = vproj_modal_kernel<T, M_>;
+    dim3 grid(xcd_grid((unsigned)((a.R + 63) / 64), (unsigned)((a.N + BC - 1) / BC))), block(256);
+    auto kern = vproj_modal_kernel<T, M_, CW>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     kern<<<grid, block, smem, s>>>(a);
 }
 
 void launch_vproj(int dtype, const GemmNtArgs& a, hipStream_t s) {
+    const bool small = ((a.R + 63) / 64) * (int64_t)((a.N + 127) / 128) < 64;
     AECF_DISPATCH_M(a.M, {
-        if (dtype == 0) launch_one<BF16, M_>(a, s); else launch_one<F32, M_>(a, s);
+        if (dtype == 0) { if (small) launch_one<BF16, M_, 1>(a, s); else launch_one<BF16, M_, 4>(a, s); }
+        else { if (small) launch_one<F32, M_, 1>(a, s); else launch_one<F32, M_, 4>(a, s); }
     });
 }
 

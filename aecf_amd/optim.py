@@ -1,0 +1,64 @@
+"""AdamW of the example trainer as one launch (``aecf_adamw_step``; ref xrays/train_xrays_example.py:322-323, 376 uses
+``torch.optim.AdamW(lr=1e-4, weight_decay=0.01)``).  Same update rule and the same state layout as torch's (per parameter:
+``step`` -- a float32 scalar on the device --, ``exp_avg``, ``exp_avg_sq``), so state dicts move between the two; the step
+counters advance on the device, which makes ``step()`` capturable into a HIP graph without further flags."""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable
+
+import torch
+
+from . import _lib
+from .layer import _stream
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or not 0 < betas[0] < 1 or not 0 < betas[1] < 1 or weight_decay < 0:
+            raise ValueError("FusedAdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tickets = {}
+
+    def _ticket(self, device, n):
+        need = 65 * ((n + 23) // 24)                              # AECF_ADAMW_TICKET_WORDS per launch group
+        t = self._tickets.get(device)
+        if t is None or t.numel() < need:
+            t = torch.zeros(need, dtype=torch.int32, device=device)
+            self._tickets[device] = t
+        return t
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        vp = ctypes.c_void_p
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            for p in ps:
+                if p.device.type != "cuda" or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                    raise RuntimeError("FusedAdamW: float32 parameters with dense float32 gradients on a ROCm device only "
+                                       "(no CPU fallback is provided)")
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdamW: parameters must be contiguous")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            arr = lambda ts: (vp * len(ts))(*[t.data_ptr() for t in ts])
+            b1, b2 = group["betas"]
+            _lib.check(lib.aecf_adamw_step(
+                len(ps), arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
+                arr([self.state[p]["exp_avg_sq"] for p in ps]), arr([self.state[p]["step"] for p in ps]),
+                (ctypes.c_int64 * len(ps))(*[p.numel() for p in ps]), self._ticket(dev, len(ps)).data_ptr(),
+                float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), _stream()),
+                "aecf_adamw_step")
+        return loss

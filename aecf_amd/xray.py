@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import copy
 import ctypes
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -48,6 +49,39 @@ def modality_frontend(features: torch.Tensor, drop: Optional[torch.Tensor] = Non
                                           None if drop is None else _ptr(out), _ptr(present), _stream()),
                "aecf_modality_frontend")
     return out, present
+
+
+def front_pair(image: torch.Tensor, text: torch.Tensor, uniforms: Optional[torch.Tensor] = None, missing_prob: float = 0.3,
+               drop: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = None):
+    """Both front-ends, the missing-modality decisions and the row classes in ONE launch (``aecf_front_pair``; static routing).
+    ``uniforms`` [3, rows] float32 = the draws of ``AECFModel.draw_missing`` (ref xrays/train_xrays_example.py:156-172), or
+    ``drop`` = (drop_a, drop_b) decided by the caller, or neither.  Returns ``(image_out, text_out, present_a, present_b, cls)``:
+    rows of an absent modality (dropped, zero norm, NaN) come out as zeros; ``cls`` in {BOTH, ONLY_A, ONLY_B, NONE}."""
+    _need_device(image)
+    if image.dim() != 2 or text.dim() != 2 or image.dtype not in _DTYPES or text.dtype != image.dtype \
+            or text.shape[0] != image.shape[0]:
+        raise ValueError("front_pair expects two [rows, dim] tensors of one dtype (float32 or bfloat16)")
+    lib = _lib.load()
+    a, b = image.detach().contiguous(), text.detach().contiguous()
+    rows, dev = a.shape[0], a.device
+    u = None
+    if uniforms is not None:
+        u = uniforms.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if u.shape != (3, rows):
+            raise ValueError("front_pair: uniforms must be [3, rows]")
+    da = db = None
+    if drop is not None:
+        if u is not None:
+            raise ValueError("front_pair: uniforms and drop are alternatives")
+        da = None if drop[0] is None else drop[0].to(device=dev, dtype=torch.uint8).contiguous()
+        db = None if drop[1] is None else drop[1].to(device=dev, dtype=torch.uint8).contiguous()
+    out_a, out_b = torch.empty_like(a), torch.empty_like(b)
+    marks = torch.empty(2, rows, dtype=torch.uint8, device=dev)
+    cls = torch.empty(rows, dtype=torch.int32, device=dev)
+    _lib.check(lib.aecf_front_pair(rows, a.shape[1], b.shape[1], _DTYPES[a.dtype], _ptr(a), _ptr(b), _ptr(u), float(missing_prob),
+                                   _ptr(da), _ptr(db), _ptr(out_a), _ptr(out_b), marks[0].data_ptr(), marks[1].data_ptr(),
+                                   _ptr(cls), _stream()), "aecf_front_pair")
+    return out_a, out_b, marks[0], marks[1], cls
 
 
 class Route:
@@ -179,6 +213,36 @@ class _BranchSelect(torch.autograd.Function):
         return grads[0], grads[1], grads[2], None, None
 
 
+class _StaticSelect(torch.autograd.Function):
+    """Static routing: every branch produced a row for EVERY sample; fused[r] = the row of the branch that owns r (zeros for a
+    row with no modality) in one pass, and the gradient of fused[r] goes to that branch alone (zeros to the others) in one
+    more -- what three ``torch.where`` + two adds and their backward nodes do in the tensor formulation."""
+
+    @staticmethod
+    def forward(ctx, both, only_a, only_b, cls):
+        parts = [p.contiguous() for p in (both, only_a, only_b)]
+        rows, width = parts[0].shape
+        es = parts[0].element_size()
+        out = torch.empty_like(parts[0])
+        lib = _lib.load()
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        _lib.check(lib.aecf_rows_select(rows, width * es, _ptr(cls), None, _arr(vp, [p.data_ptr() for p in parts]),
+                                        _arr(i64, [width * es] * 3), _ptr(out), width * es, _stream()), "aecf_rows_select")
+        ctx.save_for_backward(cls)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (cls,) = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        rows, width = d_out.shape
+        grads = [torch.empty_like(d_out) for _ in range(3)]
+        lib = _lib.load()
+        _lib.check(lib.aecf_rows_split(rows, width * d_out.element_size(), _ptr(cls), _ptr(d_out),
+                                       _arr(ctypes.c_void_p, [g.data_ptr() for g in grads]), _stream()), "aecf_rows_split")
+        return grads[0], grads[1], grads[2], None
+
+
 class AECFModel(nn.Module):
     """Image + text multi-label classifier around the fusion pool (behaviour of ref xrays/train_xrays_example.py:108-237;
     module names and construction order as there, so seeds and checkpoints carry over)."""
@@ -229,15 +293,22 @@ class AECFModel(nn.Module):
         a shared-seed generator (``draw_missing``) and hands every rank its rows, so that which rows lose a modality does not
         depend on the number of ranks (as for the mask uniforms); without it they are drawn here."""
         drop_a = drop_b = None
-        if self.training and self.missing_modality_training:
+        simulate = self.training and self.missing_modality_training
+        if self.static_routing:
+            # one launch for both front-ends, the decisions and the row classes; the draws are draw_missing's three uniform
+            # vectors (one torch.rand node: its offset advances under graph replay)
+            u = None
+            if simulate and missing is None:
+                u = torch.rand(3, image_features.size(0), device=image_features.device, generator=generator)
+            xa, xb, _, _, cls = front_pair(image_features, text_features, u, 0.3, missing if simulate else None)
+            return self._forward_static(xa, xb, cls, return_info, mask_uniforms, generator)
+        if simulate:
             if missing is not None:
                 drop_a, drop_b = missing
             else:
                 drop_a, drop_b = self.draw_missing(image_features.size(0), image_features.device, generator=generator)
         image_features, has_a = modality_frontend(image_features, drop_a)
         text_features, has_b = modality_frontend(text_features, drop_b)
-        if self.static_routing:
-            return self._forward_static(image_features, text_features, has_a, has_b, return_info, mask_uniforms, generator)
         route = Route(has_a, has_b)
         enc_a = self.image_encoder(image_features)
         enc_b = self.text_encoder(text_features)
@@ -268,27 +339,22 @@ class AECFModel(nn.Module):
         return (logits, info) if return_info else logits
 
 
-def _forward_static(self, image_features, text_features, has_a, has_b, return_info, mask_uniforms, generator):
+def _forward_static(self, image_features, text_features, cls, return_info, mask_uniforms, generator):
+    """Every row runs every branch; ``image_features`` / ``text_features`` come from ``front_pair``: an ABSENT modality's rows
+    are zeros there, so its features never reach a weight (compact routing never touches them; presence = norm > 1e-6, ref
+    :202-203, is False for NaN / Inf rows, and 0 * NaN = NaN would poison the batch sums of every parameter gradient)."""
     rows = image_features.size(0)
-    a, b = has_a.bool(), has_b.bool()
-    # every row runs every branch here, so an ABSENT modality's features must not reach a weight: compact routing never
-    # touches them (presence = norm > 1e-6, ref :202-203, is False for NaN / Inf rows), and 0 * NaN = NaN would poison the
-    # batch sums of every parameter gradient.  Absent rows enter the encoders as zeros, branches are chosen with where.
-    zero = image_features.new_zeros(())
-    enc_a = self.image_encoder(torch.where(a.unsqueeze(1), image_features, zero))
-    enc_b = self.text_encoder(torch.where(b.unsqueeze(1), text_features, zero.to(text_features.dtype)))
+    enc_a = self.image_encoder(image_features)
+    enc_b = self.text_encoder(text_features)
     pairs = torch.stack([enc_a, enc_b], dim=1)                                   # [rows, 2, E] (what ref :213-214 stacks)
     pooled, pool_info = self.attention_pool(self.fusion_query.expand(rows, -1, -1), pairs, pairs, return_info=True,
                                             uniforms=mask_uniforms, generator=generator)
-    both, only_a, only_b = (a & b).unsqueeze(1), (a & ~b).unsqueeze(1), (b & ~a).unsqueeze(1)
-    z = enc_a.new_zeros(())
-    fused = torch.where(both, self.fusion_proj(pooled.squeeze(1)), z) + torch.where(only_a, self.image_proj(enc_a), z) \
-        + torch.where(only_b, self.text_proj(enc_b), z)
+    fused = _StaticSelect.apply(self.fusion_proj(pooled.squeeze(1)), self.image_proj(enc_a), self.text_proj(enc_b), cls)
     logits = self.classifier(fused)
     if not return_info:
         return logits
     info = dict(pool_info)
-    info["both"] = a & b
+    info["both"] = cls == BOTH
     return logits, info
 
 
@@ -307,13 +373,27 @@ class GraphedTrainStep:
     (data-parallel callers capture per rank and all-reduce between backward and step themselves)."""
 
     def __init__(self, model: AECFModel, optimizer: torch.optim.Optimizer, criterion: nn.Module, batch: int, image_dim: int,
-                 text_dim: int, num_classes: int, device, dtype=torch.float32, warmup: int = 3):
+                 text_dim: int, num_classes: int, device, dtype=torch.float32, warmup: int = 3, tune_gemm: bool = False):
         """Side effects, all deliberate: ``model.static_routing`` is set to True and stays so (the captured shapes depend on
         it); the device generator advances by the warm-up and capture draws.  NOT a side effect: the warm-up and capture
         steps run real optimisation steps on noise, so the model's parameters and buffers and the optimizer's state
         (moments, step counters) are snapshotted before them and restored afterwards -- the first replay starts from exactly
-        the state the caller handed over."""
+        the state the caller handed over.
+
+        ``tune_gemm``: the nn.Linear layers around the pool run on torch's BLAS dispatch, whose default pick for a batch of 64
+        is a 256 x 64 macro-tile kernel of 26-33 us per GEMM (profiles/r04_c4_notes.md); with this flag torch's TunableOp times
+        the rocBLAS / hipBLASLt candidates for each shape during the warm-up steps (process-wide switch, left enabled with
+        tuning off, so the capture and later calls use the recorded picks and nothing is tuned under capture)."""
         model.static_routing = True
+        if tune_gemm:
+            import torch.cuda.tunable as tunable
+            tunable.enable(True)
+            tunable.tuning_enable(True)
+            if hasattr(tunable, "write_file_on_exit"):
+                tunable.write_file_on_exit(False)
+            else:                                             # (this torch writes its picks at exit: not into the caller's directory)
+                import tempfile
+                tunable.set_filename(os.path.join(tempfile.gettempdir(), "aecf_tunableop.csv"))
         self.model, self.optimizer, self.criterion = model, optimizer, criterion
         self.image = torch.zeros(batch, image_dim, device=device, dtype=dtype)
         self.text = torch.zeros(batch, text_dim, device=device, dtype=dtype)
@@ -329,6 +409,9 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
+        if tune_gemm:
+            torch.cuda.synchronize(device)
+            tunable.tuning_enable(False)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._step()

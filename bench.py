@@ -307,6 +307,7 @@ def bench_c4(args):
     import torch.distributed as dist
     from aecf_amd import dp
     from aecf_amd.xray import AECFModel, train_step
+    from aecf_amd.optim import FusedAdamW
     from aecf_amd.train_xray import synthetic_split
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -337,11 +338,11 @@ def bench_c4(args):
         if world > 1:
             sys.exit("--graph captures a one-rank step")
         from aecf_amd.xray import GraphedTrainStep
-        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, capturable=True, fused=True)     # one optimizer kernel per dtype group instead of ~10 foreach launches
+        opt = FusedAdamW(params, lr=1e-4, weight_decay=0.01)       # one launch, device-side step counters (aecf_adamw_step)
         crit = torch.nn.BCEWithLogitsLoss()
-        graphed = GraphedTrainStep(model, opt, crit, B, 512, 512, 15, device)
+        graphed = GraphedTrainStep(model, opt, crit, B, 512, 512, 15, device, tune_gemm=not args.no_tune_gemm)
     else:
-        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
+        opt = FusedAdamW(params, lr=1e-4, weight_decay=0.01)
         crit = torch.nn.BCEWithLogitsLoss()
 
     def one_step():
@@ -381,6 +382,8 @@ def bench_c4(args):
                        "global_batch": B * world, "parallelism": f"dp{world}", "world_size": world,
                        "collectives": None if world == 1 else f"{backend}: one flat all-reduce of all {sum(p.numel() for p in params)} gradients"},
             "roofline": None,
+            "gemm_selection": ("torch TunableOp: rocBLAS / hipBLASLt candidates timed per nn.Linear shape during the warm-up"
+                               if graphed is not None and not args.no_tune_gemm else "torch default"),
             "host_enqueue_ms": enqueue / args.steps * 1e3,
             "device_tail_ms": max(0.0, (elapsed - enqueue) / args.steps * 1e3),
             "note": ("one graph replay per step: the host only copies the batch into the captured buffers and launches the graph; "
@@ -402,6 +405,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["c4"])
     ap.add_argument("--batch", type=int, default=64, help="--config c4: rows per step per GPU (the reference's 64)")
+    ap.add_argument("--no-tune-gemm", action="store_true",
+                    help="c4 --graph: leave the nn.Linear GEMMs on torch's default BLAS pick (default: TunableOp during warm-up)")
     ap.add_argument("--graph", action="store_true",
                     help="one rank: the whole step captured once as a HIP graph and replayed (c4: static routing; the pool "
                          "configurations: forward + entropy loss + backward; meant for the host-bound shards)")

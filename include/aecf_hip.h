@@ -358,6 +358,32 @@ int aecf_rows_select(int64_t rows, int64_t row_bytes, const int32_t* route, cons
                      const void* const* src, const int64_t* src_pitch, void* dst, int64_t dst_pitch,
                      void* stream);
 
+/* ---- static routing (every branch keeps all rows, so a whole step has fixed shapes and can be one HIP graph) ----
+ *   aecf_front_pair: both modality front-ends, the missing-modality decisions (ref :156-172) and the row classes in one
+ *     launch.  Decisions come from uniforms [3, rows] (a dropped if u0 < missing_prob, b if u1 < missing_prob; a row that
+ *     would lose both keeps a when u2 > 0.5, else b), or from drop_a / drop_b (either may be NULL), or none (all three
+ *     NULL).  present_x = not dropped and ||row|| > 1e-6 (float32; false for NaN rows, as torch.norm(...) > 1e-6 is, :202-203);
+ *     out_x = the row if present_x else zeros (out_x != feat_x); cls as aecf_route_build's route.
+ *   aecf_rows_select with slot == NULL reads src_c[r] (identity slots): fused[r] = the row of the branch that owns r.
+ *   aecf_rows_split: its backward, dst_c[r] = src[r] if route[r] == c else zeros, c = 0..2 (NULL dst_c skipped), one launch. */
+int aecf_front_pair(int64_t rows, int32_t dim_a, int32_t dim_b, int32_t dtype, const void* feat_a, const void* feat_b,
+                    const float* uniforms, float missing_prob, const uint8_t* drop_a, const uint8_t* drop_b,
+                    void* out_a, void* out_b, uint8_t* present_a, uint8_t* present_b, int32_t* cls, void* stream);
+int aecf_rows_split(int64_t rows, int64_t row_bytes, const int32_t* route, const void* src, void* const* dst,
+                    void* stream);
+
+/* ---- the example trainer's optimiser step (ref xrays/train_xrays_example.py:322-323, 376: torch.optim.AdamW) ----
+ * AdamW (decoupled weight decay, no amsgrad) over n float32 tensors in one launch per 24 tensors: arrays of n device
+ * pointers (param, grad, exp_avg, exp_avg_sq: numel[i] floats each; step[i]: ONE float, the number of steps taken so far,
+ * advanced on the device so that a captured step replays with a fresh count) and ticket = AECF_ADAMW_TICKET_WORDS * ((n + 23) / 24)
+ * zero-initialised uint32 the launches use to find their last block (they leave them zero).  Arithmetic in float32; the bias corrections
+ * 1 - beta^t are formed as -expm1(t ln beta) in float32 (relative error ~1e-7; torch uses double on the host or, capturable,
+ * a float32 pow on the device).  beta = 0 is not supported (ln). */
+#define AECF_ADAMW_TICKET_WORDS 65
+int aecf_adamw_step(int32_t n, void* const* param, const void* const* grad, void* const* exp_avg,
+                    void* const* exp_avg_sq, void* const* step, const int64_t* numel, void* ticket, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* ---- contrastive term (BASELINE.json north_star; NOT in the reference: SURVEY.md 8a row A9, build-defined) ----
  * Row-wise L2 normalisation zn = z / max(||z||, eps) and its backward dz = (dzn - zn (dzn.zn)) * inv_norm. */
 int aecf_l2norm_forward(int64_t n, int32_t d, int32_t dtype, float eps, const void* z, void* zn,

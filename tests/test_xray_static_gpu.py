@@ -175,3 +175,57 @@ def test_static_routing_ignores_non_finite_features_of_absent_modalities():
         assert torch.isfinite(q.grad).all(), n         # static routing feeds absent rows to the encoders as zeros
         if "encoder" not in n:                         # (compact routing, like the reference, runs the encoders on every row:
             assert rel_err(q.grad.cpu(), p.grad.cpu()) < 2e-5, n      #  its encoder weight gradients are NaN here)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_front_pair_equals_the_separate_front_ends(dtype):
+    """aecf_front_pair against draw_missing + modality_frontend x 2 + the presence classes, on the same uniforms; rows with a NaN,
+    an all-zero and a dropped modality included."""
+    from aecf_amd.xray import AECFModel, Route, front_pair, modality_frontend
+    dev = torch.device("cuda:0")
+    n = 333
+    g = torch.Generator().manual_seed(11)
+    image = torch.randn(n, 512, generator=g).to(dev, dtype)
+    text = torch.randn(n, 320, generator=g).to(dev, dtype)
+    image[4::9] = 0.0
+    text[5::11] = 0.0
+    image[7, 100] = float("nan")
+    text[8, 3] = float("inf")
+    model = AECFModel(512, 320, 15)
+    gen = torch.Generator(device=dev).manual_seed(21)
+    drop_a, drop_b = model.draw_missing(n, dev, generator=gen)
+    gen.manual_seed(21)
+    u = torch.rand(3, n, device=dev, generator=gen)
+    ref_a, has_a = modality_frontend(image, drop_a)
+    ref_b, has_b = modality_frontend(text, drop_b)
+    route = Route(has_a, has_b)
+    for kwargs in (dict(uniforms=u), dict(drop=(drop_a, drop_b))):
+        xa, xb, pa, pb, cls = front_pair(image, text, missing_prob=0.3, **kwargs)
+        assert torch.equal(pa, has_a) and torch.equal(pb, has_b)
+        assert torch.equal(cls, route.cls)
+        za, zb = torch.zeros_like(ref_a), torch.zeros_like(ref_b)
+        assert torch.equal(xa, torch.where(has_a.bool().unsqueeze(1), ref_a, za))
+        assert torch.equal(xb, torch.where(has_b.bool().unsqueeze(1), ref_b, zb))
+    assert 0 < int(drop_a.sum()) < n and int((drop_a & drop_b).sum()) == 0
+    # no decisions at all: presence alone
+    xa, xb, pa, pb, cls = front_pair(image, text)
+    _, qa = modality_frontend(image)
+    _, qb = modality_frontend(text)
+    assert torch.equal(pa, qa) and torch.equal(pb, qb)
+    assert not bool(torch.isnan(xa).any())            # (the Inf row of text counts as present: norm = inf > 1e-6)
+
+
+def test_static_select_and_its_backward():
+    from aecf_amd.xray import _StaticSelect
+    dev = torch.device("cuda:0")
+    n, w = 157, 512
+    g = torch.Generator().manual_seed(4)
+    parts = [torch.randn(n, w, generator=g).to(dev).requires_grad_() for _ in range(3)]
+    cls = torch.randint(0, 4, (n,), generator=g).to(dev, torch.int32)
+    out = _StaticSelect.apply(*parts, cls)
+    ref = sum(torch.where((cls == c).unsqueeze(1), parts[c], torch.zeros((), device=dev)) for c in range(3))
+    assert torch.equal(out, ref)
+    d = torch.randn(n, w, generator=g).to(dev)
+    out.backward(d)
+    for c in range(3):
+        assert torch.equal(parts[c].grad, torch.where((cls == c).unsqueeze(1), d, torch.zeros((), device=dev)))
