@@ -592,10 +592,14 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = (char*)a->dw_in + (size_t)2 * E * E * gsz; rs.n[2] = (int64_t)E * E;
     rs.src[3] = (const float*)(ws + L.cs_v);   rs.dst[3] = (char*)a->db_in + (size_t)2 * E * gsz;  rs.n[3] = E;
     rs.src[4] = (const float*)(ws + L.u_slab); rs.dst[4] = u;                                      rs.n[4] = (int64_t)H * E;
-    if (!u_reduced) {                                                  // u first, on its own: every finalize block reads all of it
-        ReduceSegs ru = rs;
-        for (int i = 0; i < 4; ++i) ru.n[i] = 0;
-        launch_reduce_segments(ru, s);
+    if (!u_reduced) {                                                  // u first: every finalize block reads all of it
+        if (!dqp_rides && rs.splits[4] <= 8) {                         // a few slabs: the dq' launch adds them up as it reads them
+            dq.u_slab = (const float*)(ws + L.u_slab); dq.u_nslab = rs.splits[4]; dq.u_out = u;
+        } else {
+            ReduceSegs ru = rs;
+            for (int i = 0; i < 4; ++i) ru.n[i] = 0;
+            launch_reduce_segments(ru, s);
+        }
     }
     rs.n[4] = 0;
     if (!dqp_rides) launch_dqp(d->dtype, dq, s);

@@ -142,6 +142,11 @@ struct DqpJob {
     float* dqp = nullptr;         // [E]
     float scale = 0.f;
     int E = 0, hd = 1;
+    // optional (stand-alone launch, a few slabs): u is still in u_nslab partial slabs [u_nslab][H, E]; every row adds them up for
+    // its head on the fly and the first row of a head writes the sums to u_out [H, E] (what the finalize launch reads)
+    const float* u_slab = nullptr;
+    float* u_out = nullptr;
+    int u_nslab = 0;
 };
 
 template <typename T>
@@ -151,14 +156,32 @@ __device__ __forceinline__ void dqp_rows(const DqpJob& q, int block, int nblocks
     const int j0 = block * per, j1 = (j0 + per) < q.E ? (j0 + per) : q.E;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (int)blockDim.x >> 6;
     for (int j = j0 + w; j < j1; j += nw) {                        // (wave-uniform bounds: whole waves take the butterfly)
-        const float* u = q.u + (int64_t)(j / q.hd) * q.E;
+        const int64_t urow = (int64_t)(j / q.hd) * q.E;
+        const float* u = q.u + urow;
         const typename X::elem* wr = reinterpret_cast<const typename X::elem*>(q.w_k) + (int64_t)j * q.E;
         float a = 0.f;
         for (int c = lane * 8; c < q.E; c += 512) {
             float wv[8];
             X::load4(wr + c, wv);
             X::load4(wr + c + 4, wv + 4);
-            const f32x4 u0 = *reinterpret_cast<const f32x4*>(u + c), u1 = *reinterpret_cast<const f32x4*>(u + c + 4);
+            f32x4 u0, u1;
+            if (q.u_slab) {
+                u0 = u1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int64_t he = (int64_t)(q.E / q.hd) * q.E;
+                for (int sl = 0; sl < q.u_nslab; ++sl) {           // (fixed slab order: deterministic)
+                    const float* us = q.u_slab + sl * he + urow + c;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(us), p1 = *reinterpret_cast<const f32x4*>(us + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { u0[e] += p0[e]; u1[e] += p1[e]; }
+                }
+                if (j % q.hd == 0) {
+                    *reinterpret_cast<f32x4*>(q.u_out + urow + c) = u0;
+                    *reinterpret_cast<f32x4*>(q.u_out + urow + c + 4) = u1;
+                }
+            } else {
+                u0 = *reinterpret_cast<const f32x4*>(u + c);
+                u1 = *reinterpret_cast<const f32x4*>(u + c + 4);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) a = fmaf(wv[e], u0[e], a);
 #pragma unroll

@@ -218,8 +218,10 @@ class _PoolFunction(torch.autograd.Function):
         # partial sums of the entropy regulariser over this call's rows, left behind by the kernel that writes the entropies
         # (training mode): CurriculumMasking.entropy_loss(info['entropy']) is then one small launch (side = a dict of the caller)
         # ... and, ABI v8, the loss itself: the out-projection launch's first block adds the partials up (no launch at all)
+        # bf16 only: there the sums ride in kernels that run anyway; the float32 kernels would need two launches of their own for
+        # them, which a caller that never asks for the regulariser (the example model's step) pays for nothing
         ent_partial = ent_loss = None
-        if side is not None and mask_mode == 1 and target_value is not None:
+        if side is not None and mask_mode == 1 and target_value is not None and dt == torch.bfloat16:
             ent_partial = torch.empty((B + 255) // 256, dtype=torch.float32, device=dev)
             if not f32_info:
                 ent_loss = torch.empty(1, dtype=dt, device=dev)

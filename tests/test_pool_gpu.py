@@ -774,7 +774,7 @@ def test_entropy_loss_from_the_forward_partial_sums(dtype, B, M, E, H):
     x = (torch.randn(B, M, E, device=dev) * torch.linspace(0.5, 3.0, M, device=dev).view(1, M, 1)).to(dtype)
     out, info = pool(query.expand(B, -1, -1), x, return_info=True)
     ent = info["entropy"]
-    assert hasattr(ent, "_aecf_entropy_partials")
+    assert hasattr(ent, "_aecf_entropy_partials") == (dtype == torch.bfloat16)     # (float32: the stand-alone operator runs)
     cm = pool.curriculum_masking
     fast = cm.entropy_loss(ent)
     plain = cm.entropy_loss(ent.clone())
