@@ -24,3 +24,14 @@ python3 bench.py --config c5 --steps 50 --warmup 10 --no-cpu-baseline > $out/${t
 for f in c2 c3shard c5shard; do python3 -c "
 import json; l=json.load(open('$out/${tag}_${f}_bench.json')); r=l['roofline']
 print('$f', round(l['ms_per_step'],4), round(l['value']/1e6,1), 'M/s', r['kernel'], round(r['frac'],3), r['traffic'], round(l['path_hbm_frac'],3), round(l['path_mfma_frac'],3))"; done
+# configs[3] (the example model): captured step and eager step at the reference's batch and at a device-bound batch
+python3 bench.py --config c4 --batch 64 --graph --steps 300 --warmup 20 > $out/${tag}_c4_b64_graph_bench.json 2> /dev/null
+python3 bench.py --config c4 --batch 16384 --graph --steps 100 --warmup 10 > $out/${tag}_c4_b16384_graph_bench.json 2> /dev/null
+python3 bench.py --config c4 --batch 64 --steps 100 --warmup 10 > $out/${tag}_c4_b64_bench.json 2> /dev/null
+python3 bench.py --config c4 --batch 16384 --steps 100 --warmup 10 > $out/${tag}_c4_b16384_bench.json 2> /dev/null
+for f in c4_b64_graph c4_b16384_graph c4_b64 c4_b16384; do python3 -c "
+import json; l=json.load(open('$out/${tag}_${f}_bench.json'))
+print('$f', round(l['ms_per_step'],4), 'host', round(l['host_enqueue_ms'],3), 'tail', round(l['device_tail_ms'],3))"; done
+rocprofv3 --kernel-trace --stats -d $out/ks4 -o r -- python3 bench.py --settle-seconds 0 --config c4 --batch 64 --graph --steps 20 --warmup 5 > /dev/null 2>&1
+python3 tools/kernel_stats_from_db.py $out/ks4/r_results.db $out/${tag}_c4_b64_graph_kernel_stats.csv | head -8
+rm -rf $out/ks4
