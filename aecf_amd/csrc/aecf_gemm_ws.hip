@@ -1483,6 +1483,15 @@ bool launch_dx2_hk(const BwdGArgs& a, hipStream_t s) {
 // bank-conflict free for ds_read_b128's lane grouping.
 // Measured (C2, same-box A/B, 3 pairs): value projection 118 -> 114 us, step -0.6 %: the second barrier was a small part
 // of the score phase; its MFMAs, the partial sums' trip through LDS and the softmax remain.
+#ifdef AECF_WS_TIMELINE
+// experiment build only (tools/debug/ws_timeline.py): shader-clock stamps of a few waves at the phase boundaries of every step
+// (a stamp costs ~150 cycles and drains lgkmcnt: compare phases between waves and builds, not against the untimed kernel)
+__device__ unsigned long long g_ws_timeline[8 * 64 * 8];
+#define WS_STAMP(slot) do { if (tl_on && step_no < 64) tl[step_no * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_STAMP(slot) do { } while (0)
+#endif
+
 template <int M_>
 __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;
@@ -1595,12 +1604,21 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
     for (int kg = 0; kg < KG; ++kg) asm volatile("" : "+v"(ga[kg][0]), "+v"(ga[kg][1]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // own slab of the first tile landed
     scores(0, gpart);
+#ifdef AECF_WS_TIMELINE
+    const int tl_wsel = (w % 2 == 1) ? w / 2 : -1;                 // waves 1, 3, 5, 7 of blocks 0 and 133
+    const int tl_bsel = blockIdx.x == 0 ? 0 : (blockIdx.x == 133 ? 1 : -1);
+    const bool tl_on = lane == 0 && tl_wsel >= 0 && tl_bsel >= 0;
+    unsigned long long* tl = g_ws_timeline + (tl_bsel * 4 + (tl_wsel < 0 ? 0 : tl_wsel)) * 64 * 8;
+    int step_no = 0;
+#endif
 
     int cur = 0;
     for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
         const bool more = o0 + 16 < o_end;
+        WS_STAMP(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's partial scores of this step are in LDS
         __builtin_amdgcn_s_barrier();                              // tile and partials of this step visible; other buffers free
+        WS_STAMP(1);
         if (more) load_kp(o0 + 16);
         // ---- softmax over the modalities for (this wave's head, this lane's sample); partial sums in wave order
         float pm[M_];
@@ -1630,6 +1648,7 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
                 for (int m = 0; m < M_; ++m) dst[m] = pm[m];
             }
         }
+        WS_STAMP(2);
         // ---- products: modality-major items, operand reads PF items ahead; the next tile's copy goes out among the first
         constexpr int NIT = M_ * KT, PF = AECF_VPROJ_PF;
         const char* tb = smem + cur * TILE;
@@ -1686,12 +1705,15 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
                 for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        WS_STAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slab of the next tile (and its mask bytes) landed
+        WS_STAMP(4);
 #pragma unroll
         for (int m = 0; m < M_; ++m) { asm volatile("" : "+v"(kp_next[m])); kp[m] = p.g_kpm ? kp_next[m] : 0u; }
 #ifndef AECF_ABL_NOSCORES
         if (more) scores(cur ^ 1, gpart + (cur ^ 1) * GP);         // next step's partial scores, from this wave's own slab
 #endif
+        WS_STAMP(5);
         const int64_t b = o0 + r16;
 #ifdef AECF_ABL_NOSTORE
 #pragma unroll
@@ -1708,6 +1730,10 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
             else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + NV * lg, ov);
             if (p.c_lo) store_cols_lo<CT>(reinterpret_cast<unsigned short*>(p.c_lo) + b * N + ncol0 + NV * lg, ov);
         }
+        WS_STAMP(6);
+#ifdef AECF_WS_TIMELINE
+        ++step_no;
+#endif
     }
 }
 
@@ -1876,3 +1902,9 @@ bool launch_dx_ws(const BwdGArgs& a, hipStream_t s) {
 }
 
 }  // namespace aecf
+
+#ifdef AECF_WS_TIMELINE
+extern "C" int aecf_debug_ws_timeline(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(aecf::g_ws_timeline), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
