@@ -52,6 +52,15 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                else:
+                    # a state loaded from torch.optim.AdamW keeps `step` on the host (or as a Python number) unless that optimizer
+                    # was capturable: the kernel reads and advances it on the device
+                    step = st["step"]
+                    if not torch.is_tensor(step) or step.device != p.device or step.dtype != torch.float32:
+                        st["step"] = torch.as_tensor(float(step), dtype=torch.float32, device=p.device)
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        if st[key].device != p.device or st[key].dtype != torch.float32 or not st[key].is_contiguous():
+                            st[key] = st[key].to(device=p.device, dtype=torch.float32).contiguous()
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             arr = lambda ts: (vp * len(ts))(*[t.data_ptr() for t in ts])
             b1, b2 = group["betas"]

@@ -78,6 +78,32 @@ def test_fused_adamw_replays_in_a_graph_with_a_fresh_step_count():
         assert float(ob.state[b]["step"]) == float(oa.state[a]["step"]) == 6.0
 
 
+def test_fused_adamw_continues_from_a_torch_adamw_state():
+    """A state dict written by torch.optim.AdamW (step counters on the host) loads into FusedAdamW and the next steps agree."""
+    from aecf_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    pa = _params(dev, 7)
+    oa = torch.optim.AdamW(pa, lr=2e-3, weight_decay=0.02)
+    g = torch.Generator().manual_seed(8)
+    for _ in range(3):
+        for a in pa:
+            a.grad = torch.randn(a.shape, generator=g).to(dev)
+        oa.step()
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    ob = FusedAdamW(pb, lr=2e-3, weight_decay=0.02)
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+    for _ in range(4):
+        for a, b in zip(pa, pb):
+            grad = torch.randn(a.shape, generator=g).to(dev)
+            a.grad, b.grad = grad.clone(), grad.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert rel_err(b.detach().cpu(), a.detach().cpu()) < 2e-6
+        assert float(ob.state[b]["step"]) == float(oa.state[a]["step"]) == 7.0
+        assert ob.state[b]["step"].device == b.device
+
+
 def test_fused_adamw_refuses_cpu_parameters():
     from aecf_amd.optim import FusedAdamW
     p = torch.zeros(4, requires_grad=True)
