@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import dp
+from .optim import FusedAdamW
 from .xray import AECFModel
 
 
@@ -110,7 +111,7 @@ def main(argv=None):
     params = list(model.parameters())
     dp.broadcast_parameters(params + list(model.buffers()))
     bucket = dp.FlatGradBucket(params) if world > 1 else None
-    opt = torch.optim.AdamW(params, lr=args.lr, weight_decay=0.01)          # ref :322-323
+    opt = FusedAdamW(params, lr=args.lr, weight_decay=0.01)                 # ref :322-323 (torch.optim.AdamW's update, one launch)
     crit = torch.nn.BCEWithLogitsLoss()
     n = image.shape[0]
     steps = (n + args.batch - 1) // args.batch                              # the short last batch is kept (DataLoader default)
