@@ -43,6 +43,16 @@ namespace {
 
 enum { WS_PLAIN = 0, WS_VPROJ = 1, WS_VFLAT = 2 };
 
+#ifdef AECF_WS_TIMELINE
+// experiment build only (tools/debug/ws_timeline.py): shader-clock stamps of a few waves at the phase boundaries of every step
+// (a stamp costs ~150 cycles and drains lgkmcnt: compare phases between waves and builds, not against the untimed kernel)
+__device__ unsigned long long g_ws_timeline[2 * 8 * 64 * 8]      /* [kernel: 0 vproj_slab, 1 dsu_ws][8 waves][64 steps][8 stamps] */;
+#define WS_STAMP(slot) do { if (tl_on && step_no < 64) tl[step_no * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_STAMP(slot) do { } while (0)
+#endif
+
+
 #ifndef AECF_WS_PLAIN_BUFS
 #define AECF_WS_PLAIN_BUFS 2
 #endif
@@ -880,9 +890,18 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef AECF_WS_TIMELINE
+    const int tl_wsel = (w % 2 == 0) ? w / 2 : -1;                 // waves 0, 2, 4, 6 of blocks 0 and 133
+    const int tl_bsel = blockIdx.x == 0 ? 0 : (blockIdx.x == 133 ? 1 : -1);
+    const bool tl_on = lane == 0 && tl_wsel >= 0 && tl_bsel >= 0;
+    unsigned long long* tl = g_ws_timeline + (8 + tl_bsel * 4 + (tl_wsel < 0 ? 0 : tl_wsel)) * 64 * 8;
+    int step_no = 0;
+#endif
     int cur = 0;
     for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
+        WS_STAMP(0);
         __builtin_amdgcn_s_barrier();                              // this step's tiles visible; the other buffers free
+        WS_STAMP(1);
         if (o0 + 16 < o_end) {
             issue(o0 + 16, cur ^ 1);
             load_stats(o0 + 16, pmv_n, dwb_n);
@@ -993,8 +1012,10 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 }
             }
         }
+        WS_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        WS_STAMP(3);
         asm volatile("" : "+v"(pmv), "+v"(dwb));
         if (w < HBL) {                               // whole waves: the lane-group sum below needs every lane
             float da = 0.f;
@@ -1024,8 +1045,10 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 dsl[ds_hh * DSROW + kslot(ds_s, ds_m)] = X::from_f32(d - X::to_f32(hi));
             }
         }
+        WS_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        WS_STAMP(5);
         // u^T[k, h] += x^T[k, (b,m)] ds[(b,m), h]:  A operand by transposed reads of the x tile (rows = K index)
 #pragma unroll
         for (int ks = 0; ks < KU; ++ks) {
@@ -1039,7 +1062,12 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 uacc[ct] = X::mma(af, bl, uacc[ct]);
             }
         }
+        WS_STAMP(6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tiles and statistics landed (a whole step to do so)
+        WS_STAMP(7);
+#ifdef AECF_WS_TIMELINE
+        ++step_no;
+#endif
         asm volatile("" : "+v"(pmv_n), "+v"(dwb_n));
         pmv = pmv_n; dwb = dwb_n;
     }
@@ -1483,15 +1511,6 @@ bool launch_dx2_hk(const BwdGArgs& a, hipStream_t s) {
 // bank-conflict free for ds_read_b128's lane grouping.
 // Measured (C2, same-box A/B, 3 pairs): value projection 118 -> 114 us, step -0.6 %: the second barrier was a small part
 // of the score phase; its MFMAs, the partial sums' trip through LDS and the softmax remain.
-#ifdef AECF_WS_TIMELINE
-// experiment build only (tools/debug/ws_timeline.py): shader-clock stamps of a few waves at the phase boundaries of every step
-// (a stamp costs ~150 cycles and drains lgkmcnt: compare phases between waves and builds, not against the untimed kernel)
-__device__ unsigned long long g_ws_timeline[8 * 64 * 8];
-#define WS_STAMP(slot) do { if (tl_on && step_no < 64) tl[step_no * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define WS_STAMP(slot) do { } while (0)
-#endif
-
 template <int M_>
 __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int rows_per_block, int nchunk) {
     using X = Tr<BF16>;

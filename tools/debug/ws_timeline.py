@@ -23,14 +23,28 @@ for _ in range(3):
     out.float().square().mean().backward()
 torch.cuda.synchronize()
 lib = _lib.load()
-n = 8 * 64 * 8
+n = 2 * 8 * 64 * 8
 buf = (ctypes.c_ulonglong * n)()
 if not hasattr(lib, "aecf_debug_ws_timeline"):
     sys.exit("library built without -DAECF_WS_TIMELINE")
 fn = lib.aecf_debug_ws_timeline
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rc = fn(buf, n)
-t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(8, 64, 8)
+tall = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(2, 8, 64, 8)
+# ---- dsu_ws_kernel: stamps 0 top, 1 after barrier A, 2 P + dot done, 3 after (lgkm + barrier B), 4 softmax backward done,
+#      5 after (lgkm + barrier C), 6 u product issued, 7 after vmcnt(0)
+dn = ["barrier A", "copy issue + P MFMAs + dot", "lgkm + barrier B", "softmax backward", "lgkm + barrier C", "u product", "wait vmcnt"]
+for sel in range(8):
+    tt = tall[1][sel]
+    steps = int((tt[:, 0] > 0).sum())
+    if steps < 4:
+        continue
+    tt = tt[:steps]
+    d = np.diff(tt, axis=1)
+    step_len = tt[1:, 0] - tt[:-1, 0]
+    print(f"dsu_ws block sel {sel // 4} wave {2 * (sel % 4)}: {steps} steps, mean step {step_len[1:].mean():.0f} cycles:",
+          " | ".join(f"{dn[i]} {d[2:-1, i].mean():.0f}" for i in range(7)))
+t = tall[0]
 names = ["lgkm + barrier", "softmax", "MFMA loop", "wait vmcnt", "next scores", "stores"]
 for sel in range(8):
     tt = t[sel]
@@ -40,6 +54,6 @@ for sel in range(8):
     tt = tt[:steps]
     d = np.diff(tt[:, :7], axis=1)
     step_len = tt[1:, 0] - tt[:-1, 0]
-    print(f"block sel {sel // 4} wave {2 * (sel % 4) + 1}: {steps} steps, mean step {step_len[1:].mean():.0f} cycles:",
+    print(f"vproj_slab block sel {sel // 4} wave {2 * (sel % 4) + 1}: {steps} steps, mean step {step_len[1:].mean():.0f} cycles:",
           " | ".join(f"{names[i]} {d[2:-1, i].mean():.0f}" for i in range(6)), f"| loop back {(tt[1:, 0] - tt[:-1, 6])[1:].mean():.0f}")
 print("rc", rc, "first->last stamp, block 0 wave 1:", int(t[0, :, 6].max() - t[0, 0, 0]))
