@@ -96,6 +96,25 @@ def test_bench_pool_step_replays_as_one_graph():
     assert line["graph_replay"] is True and line["value"] > 0
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("extra", [["--graph"], ["--graph", "--no-tune-gemm"], []])
+def test_bench_example_model_step(extra):
+    """`bench.py --config c4`: the example model's optimisation step, captured (static routing, FusedAdamW inside the graph, the
+    nn.Linear GEMMs picked by TunableOp during the warm-up or left on torch's default) and eager."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4", "--batch", "64", "--steps", "10", "--warmup", "3"]
+                       + extra, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["value"] > 0 and line["dtype"] == "f32" and line["config"]["global_batch"] == 64
+    assert ("captured" in line["config"]["workload"]) == ("--graph" in extra)
+    assert ("TunableOp" in line["gemm_selection"]) == (extra == ["--graph"])
+
+
 def test_graphed_step_keeps_a_trained_optimizers_state():
     """A GraphedTrainStep built around an optimizer that has already stepped gives its moments and step counters back."""
     from aecf_amd.xray import AECFModel, GraphedTrainStep, train_step
