@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AECF_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box); default = the in-tree build
 LIB_PATH = os.environ.get("AECF_LIB_PATH") or os.path.join(_HERE, "lib", "libaecf_hip.so")
 
-AECF_ABI_VERSION = 8
+AECF_ABI_VERSION = 9
 AECF_BF16 = 0
 AECF_F32 = 1
 AECF_PRECISE = 1
@@ -22,10 +22,6 @@ AECF_HILO_GRADS = 4
 AECF_FWD_STAGES = 4
 AECF_BWD_STAGES = 8
 
-# profiling hook (bench.py): arrays of hipEvent_t handles the next forward / backward call records at its
-# stage boundaries (see include/aecf_hip.h).  None = off (always, outside bench.py).
-stage_events_fwd = None
-stage_events_bwd = None
 
 
 class PoolDesc(Structure):
@@ -56,7 +52,7 @@ class PoolFwdArgs(Structure):
         ("info_target_entropy", c_void_p), ("target_entropy_value", c_float), ("flags", c_int32),
         ("ent_loss_partial", c_void_p),
         ("philox_seed", c_uint64), ("philox_offset", c_uint64), ("philox_threads", c_uint32), ("ent_loss", c_void_p),
-        ("saved_o_lo", c_void_p),
+        ("saved_o_lo", c_void_p), ("philox_element0", c_int64),
     ]
 
 
@@ -70,7 +66,7 @@ class PoolBwdArgs(Structure):
         ("db_out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("stage_events", c_void_p),
         ("grad_dtype", c_int32), ("flags", c_int32), ("saved_prep", c_void_p), ("param_grads_event", c_void_p),
-        ("saved_o_lo", c_void_p),
+        ("saved_o_lo", c_void_p), ("grad_scale", c_float),
     ]
 
 
@@ -107,7 +103,7 @@ _SYMBOLS = [
     ("aecf_pool_hilo_bwd_workspace_bytes", c_size_t, [POINTER(PoolDesc)]),
     ("aecf_pool_wants_saved_v", c_int, [POINTER(PoolDesc)]),
     ("aecf_pool_precise_workspace_bytes", c_size_t, [POINTER(PoolDesc), c_int]),
-    ("aecf_philox_uniforms", c_int, [c_int64, c_uint64, c_uint64, c_uint32, c_void_p, c_void_p]),
+    ("aecf_philox_uniforms", c_int, [c_int64, c_uint64, c_uint64, c_uint32, c_int64, c_void_p, c_void_p]),
     ("aecf_philox_host", c_float, [c_uint64, c_uint64, c_uint32, c_int64, c_void_p]),
     ("aecf_pool_forward", c_int, [POINTER(PoolDesc), POINTER(PoolFwdArgs), c_void_p]),
     ("aecf_pool_backward", c_int, [POINTER(PoolDesc), POINTER(PoolBwdArgs), c_void_p]),

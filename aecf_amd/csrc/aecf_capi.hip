@@ -82,10 +82,7 @@ BwdWs bwd_layout(const aecf_pool_desc* d, bool hilo = false) {
     w.splits = S;
     w.rows_per_split = rps;
     {   // u = ds^T x: [16, E] per batch split, ~512 blocks of 8 waves (2 per CU)
-#ifndef AECF_USU
-#define AECF_USU 512
-#endif
-        int Su = AECF_USU;
+        int Su = 512;
         const int64_t max_su = (int64_t)((B + 63) / 64);
         if (Su > max_su) Su = (int)max_su;
         if (Su < 1) Su = 1;
@@ -98,12 +95,11 @@ BwdWs bwd_layout(const aecf_pool_desc* d, bool hilo = false) {
     size_t off = w.prep.total;
     w.dobuf = off;  off = align_up(off + B * E * es);
     w.dsbuf = off;  off = align_up(off + B * d->num_heads * d->modalities * 4);
-    // AECF_HILO_GRADS: dW_o from two launches (o hi, o lo), dW_v from three (hi hi, hi lo, lo hi), db_v from two: their slabs
-    // line up behind each other and the reduction adds them all
-    w.slab_o = off; off = align_up(off + (size_t)(hilo ? 2 : 1) * S * E * E * 4);
-    w.slab_v = off; off = align_up(off + (size_t)(hilo ? 3 : 1) * S * E * E * 4);
+    // (AECF_HILO_GRADS, round 5: ONE launch per product on hi + lo tiles -- the same single slab sets as the default path)
+    w.slab_o = off; off = align_up(off + (size_t)S * E * E * 4);
+    w.slab_v = off; off = align_up(off + (size_t)S * E * E * 4);
     w.cs_o = off;   off = align_up(off + (size_t)S * E * 4);
-    w.cs_v = off;   off = align_up(off + (size_t)(hilo ? 2 : 1) * S * E * 4);
+    w.cs_v = off;   off = align_up(off + (size_t)S * E * 4);
     w.u_splits_cap = w.u_splits > 256 ? w.u_splits : 256;            // the head-split kernel writes up to 256 slabs
     w.u_slab = off; off = align_up(off + (size_t)w.u_splits_cap * HPAD * E * 4);
     w.u = off;      off = align_up(off + HPAD * E * 4);
@@ -250,7 +246,16 @@ static bool hilo_supported(const aecf_pool_desc* d) {
     if (!gemm_ws_supported(y)) return false;
     BwdGArgs g;                                                         // ... and the score gradient on dsu_ws_kernel (do_hi + do_lo)
     g.B = d->batch; g.M = d->modalities; g.E = d->embed_dim; g.H = d->num_heads; g.hd = d->embed_dim / d->num_heads;
-    return dsu_ws_chunks(g) > 0;
+    if (dsu_ws_chunks(g) <= 0) return false;
+    GemmTnArgs t;                                                       // ... and the two batch reductions on hi + lo tiles in one launch each
+    t.lhs = t.rhs = nullptr; t.probs = nullptr; t.dsbuf = nullptr; t.out = nullptr; t.colsum = nullptr; t.u = nullptr;
+    t.B = d->batch; t.M = d->modalities; t.E = d->embed_dim; t.H = d->num_heads; t.hd = d->embed_dim / d->num_heads; t.Ej = 0;
+    const BwdWs L = bwd_layout(d, true);
+    t.splits = L.splits; t.rows_per_split = L.rows_per_split; t.u_splits = 0; t.u_rows_per_split = 0;
+    t.pooled = 1;
+    if (!gemm_tn_hilo_supported(t)) return false;
+    t.pooled = 0; t.M = 1;
+    return gemm_tn_hilo_supported(t);
 }
 
 size_t aecf_pool_hilo_bwd_workspace_bytes(const aecf_pool_desc* d) {
@@ -278,7 +283,8 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
         return AECF_ERR_NULL_POINTER;
     const bool draw = d->mask_mode == 1 && !a->uniforms && (a->flags & AECF_DRAW_UNIFORMS);
     if (d->mask_mode == 1 && !a->uniforms && !draw) return AECF_ERR_NULL_POINTER;
-    if (draw && (a->philox_threads == 0 || a->philox_threads % 256 != 0 || a->philox_offset % 4 != 0)) return AECF_ERR_BAD_DIMS;
+    if (draw && (a->philox_threads == 0 || a->philox_threads % 256 != 0 || a->philox_offset % 4 != 0 || a->philox_element0 < 0))
+        return AECF_ERR_BAD_DIMS;
     const FwdWs L = fwd_layout(d);
     if (a->workspace_bytes < L.total) return AECF_ERR_WORKSPACE;
     char* ws = (char*)a->workspace;
@@ -323,7 +329,10 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     g.i_target = d->mask_mode == 1 ? a->info_target_entropy : nullptr; g.target_value = a->target_entropy_value;
     g.B = d->batch; g.M = M; g.E = E; g.H = H;
     g.mask = make_mask_cfg(d->mask_mode, d->min_active, d->base_mask_prob, d->entropy_target, d->eps, M);
-    if (draw) { g.ph.seed = a->philox_seed; g.ph.offset = a->philox_offset; g.ph.threads = a->philox_threads; }
+    if (draw) {
+        g.ph.seed = a->philox_seed; g.ph.offset = a->philox_offset; g.ph.threads = a->philox_threads;
+        g.ph.elem0 = (unsigned long long)a->philox_element0;
+    }
     GemmNtArgs v;
     v.a = a->x; v.w = (const char*)a->w_in + (size_t)2 * E * E * es;
     v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
@@ -507,11 +516,11 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     t1.colsum = (float*)(ws + L.cs_o); t1.u = nullptr; t1.B = B; t1.M = 1; t1.E = E; t1.H = H; t1.hd = hd;
     t1.Ej = 0; t1.splits = L.splits; t1.rows_per_split = L.rows_per_split; t1.pooled = 0;
     t1.u_splits = 0; t1.u_rows_per_split = 0;
-    launch_gemm_tn(d->dtype, t1, s);
-    if (hilo) {                                       // + dy^T o_lo, into the slabs behind
-        GemmTnArgs t1l = t1;
-        t1l.rhs = a->saved_o_lo; t1l.out = t1.out + (size_t)L.splits * E * E; t1l.colsum = nullptr;
-        launch_gemm_tn(d->dtype, t1l, s);
+    if (hilo) {                                       // dy^T (o_hi + o_lo): both rhs tiles of a step in one launch
+        t1.rhs_lo = a->saved_o_lo;
+        launch_gemm_tn_hilo(t1, s);
+    } else {
+        launch_gemm_tn(d->dtype, t1, s);
     }
     const int gb = a->grad_dtype == AECF_BF16 ? 1 : 0;
     mark(ev, 3, s);
@@ -567,26 +576,24 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     dq.w_k = (const char*)a->w_in + (size_t)E * E * es; dq.u = u; dq.dqp = (float*)(ws + L.dqp); dq.scale = scale; dq.E = E; dq.hd = hd;
     const bool dqp_rides = u_reduced && d->dtype == AECF_BF16;
     if (dqp_rides) t2.dq = dq;
-    launch_gemm_tn(d->dtype, t2, s);
     if (hilo) {
-        // dW_v = do_hi^T pooled_hi (above) + do_hi^T pooled_lo + do_lo^T pooled_hi; db_v = colsum(do_hi) + colsum(do_lo)
-        GemmTnArgs t2b = t2;
-        t2b.dq = DqpJob(); t2b.pool_lo = 1; t2b.out = t2.out + (size_t)L.splits * E * E; t2b.colsum = nullptr;
-        launch_gemm_tn(d->dtype, t2b, s);
-        GemmTnArgs t2c = t2;
-        t2c.dq = DqpJob(); t2c.lhs = ws + L.do_lo; t2c.out = t2.out + (size_t)2 * L.splits * E * E;
-        t2c.colsum = t2.colsum + (size_t)L.splits * E;
-        launch_gemm_tn(d->dtype, t2c, s);
+        // dW_v = do_hi^T pooled_hi + do_hi^T pooled_lo + do_lo^T pooled_hi, db_v = colsum(do_hi + do_lo): one launch that lands
+        // both lhs tiles of a step and splits the pooled rows where it forms them (aecf_gemm_tn_hilo.hip)
+        t2.lhs_lo = ws + L.do_lo;
+        launch_gemm_tn_hilo(t2, s);
+    } else {
+        launch_gemm_tn(d->dtype, t2, s);
     }
     mark(ev, 7, s);
 
     ReduceSegs rs;
     for (int i = 0; i < ReduceSegs::N; ++i) rs.splits[i] = L.splits;
     rs.splits[4] = dsu_chunks ? dsu_chunks : L.u_splits;
-    if (hilo) { rs.splits[0] = 2 * L.splits; rs.splits[2] = 3 * L.splits; rs.splits[3] = 2 * L.splits; }
     const size_t gsz = gb ? 2 : 4;                                    // bytes per parameter-gradient element
     for (int i = 0; i < ReduceSegs::N; ++i) rs.dst_bf16[i] = gb;
     rs.dst_bf16[4] = 0;                                               // u stays float32 (internal)
+    const float gscale = a->grad_scale != 0.f ? a->grad_scale : 1.f;  // (ABI v9: 1 / world of a data-parallel caller)
+    for (int i = 0; i < 4; ++i) rs.scale[i] = gscale;
     rs.src[0] = (const float*)(ws + L.slab_o); rs.dst[0] = a->dw_out;                              rs.n[0] = (int64_t)E * E;
     rs.src[1] = (const float*)(ws + L.cs_o);   rs.dst[1] = a->db_out;                              rs.n[1] = E;
     rs.src[2] = (const float*)(ws + L.slab_v); rs.dst[2] = (char*)a->dw_in + (size_t)2 * E * E * gsz; rs.n[2] = (int64_t)E * E;
@@ -608,6 +615,7 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     f.w_in = a->w_in; f.query = a->query; f.qs = qs; f.u = u; f.dqp = (float*)(ws + L.dqp);
     f.dq_part = (float*)(ws + L.dq_part); f.dw_in = a->dw_in;
     f.db_in = a->db_in; f.dquery = a->dquery; f.E = E; f.H = H; f.hd = hd; f.scale = scale; f.grad_bf16 = gb;
+    f.gscale = gscale;
     launch_finalize_all(d->dtype, f, rs, s);
     if (dx_last) {
         (void)hipEventRecord((hipEvent_t)a->param_grads_event, s);
@@ -736,11 +744,11 @@ int aecf_sdpa_backward(int64_t B, int32_t S, int32_t T, int32_t E, int32_t dtype
     return launch_status();
 }
 
-int aecf_philox_uniforms(int64_t n, uint64_t seed, uint64_t offset, uint32_t threads, float* out, void* stream) {
-    if (n <= 0 || threads == 0 || threads % 256 != 0 || offset % 4 != 0) return AECF_ERR_BAD_DIMS;
+int aecf_philox_uniforms(int64_t n, uint64_t seed, uint64_t offset, uint32_t threads, int64_t element0, float* out, void* stream) {
+    if (n <= 0 || threads == 0 || threads % 256 != 0 || offset % 4 != 0 || element0 < 0) return AECF_ERR_BAD_DIMS;
     if (!out) return AECF_ERR_NULL_POINTER;
     PhiloxDraw ph;
-    ph.seed = seed; ph.offset = offset; ph.threads = threads;
+    ph.seed = seed; ph.offset = offset; ph.threads = threads; ph.elem0 = (unsigned long long)element0;
     launch_philox_uniforms(n, ph, out, (hipStream_t)stream);
     return launch_status();
 }

@@ -206,6 +206,8 @@ __device__ __forceinline__ void dqp_rows(const DqpJob& q, int block, int nblocks
 struct PhiloxDraw {
     unsigned long long seed = 0, offset = 0;      // the generator's (seed, philox offset) BEFORE this draw
     unsigned int threads = 0;                     // T of the torch launch this draw replaces (0 = drawing off)
+    unsigned long long elem0 = 0;                 // element of that launch this call's first weight element is (a rank's rows of
+                                                  // ONE global draw: first global row * M; 0 = the call is the whole draw)
 };
 
 __device__ __host__ __forceinline__ void philox4x32_10(unsigned int c[4], unsigned int k0, unsigned int k1) {
@@ -225,9 +227,10 @@ __device__ __host__ __forceinline__ void philox4x32_10(unsigned int c[4], unsign
 }
 
 // the float32 uniform torch.rand puts at linear element li
-__device__ __host__ __forceinline__ float philox_uniform_at(const PhiloxDraw& ph, long long li) {
+__device__ __host__ __forceinline__ float philox_uniform_at(const PhiloxDraw& ph, long long local) {
+    const unsigned long long li = (unsigned long long)local + ph.elem0;
     const unsigned long long T = ph.threads, per = 4ull * T;
-    const unsigned long long it = (unsigned long long)li / per, rem = (unsigned long long)li - it * per;
+    const unsigned long long it = li / per, rem = li - it * per;
     const unsigned int ii = (unsigned int)(rem / T);
     const unsigned long long idx = rem - (unsigned long long)ii * T;
     const unsigned long long ctr = ph.offset / 4ull + it;

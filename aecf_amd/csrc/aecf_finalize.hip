@@ -54,6 +54,7 @@ __device__ __forceinline__ void reduce_segments_block(const ReduceSegs& r, int64
                 a[c] += __shfl_xor(a[c], 32, 64);
             }
             if (on && g == 0) {
+                a *= r.scale[s];
                 if (r.dst_bf16[s]) {
                     u32x2 o;
                     o[0] = pack_bf16x2(a[0], a[1]);
@@ -83,9 +84,9 @@ __device__ __forceinline__ void fin_outer_block(const FinalizeArgs& p, int kc, i
         const float qk = X::to_f32(reinterpret_cast<const typename X::elem*>(p.query)[k]);
         for (int jj = jg; jj < 16; jj += 4) {
             const int j = jb * 16 + jj;
-            const float dq = p.dqp[j];
+            const float dq = p.dqp[j] * p.gscale;
             store_grad(p.dw_in, (int64_t)j * E + k, dq * qk, p.grad_bf16);                                         // dW_q
-            store_grad(p.dw_in, (int64_t)(E + j) * E + k, p.qs[j] * p.u[(int64_t)(j / p.hd) * E + k], p.grad_bf16);   // dW_k
+            store_grad(p.dw_in, (int64_t)(E + j) * E + k, p.qs[j] * p.gscale * p.u[(int64_t)(j / p.hd) * E + k], p.grad_bf16);   // dW_k
             if (bx == 0 && c == 0 && lane == 0) {
                 store_grad(p.db_in, j, dq, p.grad_bf16);         // db_q
                 store_grad(p.db_in, E + j, 0.f, p.grad_bf16);    // db_k
@@ -129,7 +130,7 @@ __device__ __forceinline__ void fin_dquery_block(const FinalizeArgs& p, int kb, 
         float t = 0.f;
 #pragma unroll 8
         for (int r = 0; r < 32; ++r) t += scratch[r * 64 + threadIdx.x];
-        store_grad(p.dquery, kb * 64 + threadIdx.x, t, p.grad_bf16);
+        store_grad(p.dquery, kb * 64 + threadIdx.x, t * p.gscale, p.grad_bf16);
     }
 }
 

@@ -1,0 +1,430 @@
+// The two weight-gradient batch reductions on bf16 hi + lo operand pairs, ONE launch each (AECF_HILO_GRADS, round 5):
+//
+//   dW_v[j][k] = sum_b do[b][j] * P(b,k)     do = do_hi + do_lo (written by the dout kernel), P = sum_m probs x  split where it is formed
+//              = sum_b do_hi P_hi + do_hi P_lo + do_lo P_hi                    (the lo lo term is 2^-18 of the sum: dropped)
+//   dW_o[j][k] = sum_b dy[b][j] * (o_hi[b][k] + o_lo[b][k])                    (dy is an exact bf16 input: two products)
+//
+// Round 4 ran each product as its own launch of the default kernels (three for dW_v, two for dW_o: 102 -> 310 us and 47 -> 107 us
+// at the headline shape): every launch re-read its lhs tiles, re-fetched x, re-pooled the same rows and wrote its own slab set.
+// Here a block lands the hi AND lo tiles of a step, pools once in float32, writes the pooled tile as hi + lo and issues the
+// three (two) MFMAs per output fragment from the same LDS images into ONE accumulator set; the finalize launch reduces one slab
+// set, as in the default path.
+//
+// Same tile images, transposed LDS reads (ds_read_b64_tr_b16), LDS-DMA and one-step-ahead operand fetches as
+// aecf_gemm_tn_tr.hip.  What differs is the step: 32 batch rows (one MFMA K-step) instead of 64, because a step now holds
+// twice the tiles -- wide form: lhs hi + lo [32][256] x 2 buffers = 64 KB, pooled hi + lo x 4 head slots = 64 KB.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "aecf_kernels.h"
+#include "aecf_tile.h"
+#include "aecf_tr_tile.h"
+
+namespace aecf {
+
+namespace {
+
+constexpr int HRB = 32;                        // batch rows per step
+constexpr int HR_TILE = HRB * 256;             // bytes of one [32][128 bf16] tile image (the first four row groups of aecf_tr_tile.h)
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 is named as a clobber on purpose
+// LDS-DMA of [32 rows][256 B] images, one 16-byte chunk per thread: NT threads cover NT / 512 images that lie 256 bytes apart in
+// the source row (128-column sub-tiles) and HR_TILE bytes apart in LDS.  Destination lane-linear (chunk c of an image at byte
+// 16 c), the image's permutation on the per-lane source address (aecf_gemm_tn_tr.hip: dma_tile_tr_async).
+__device__ __forceinline__ void dma_hr_images(const char* __restrict__ src, unsigned int ld_bytes, int rows_valid, char* lds) {
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    const int sub = wbase >> 9;                                   // (wave-uniform)
+    const int c = threadIdx.x & 511;
+    const int row = 8 * (c >> 7) + ((c >> 2) & 7);
+    const int rowc = row < rows_valid ? row : rows_valid - 1;
+    const int logical = 4 * ((c >> 5) & 3) + ((c & 3) ^ ((row >> 2) & 3));
+    const unsigned int voff = (unsigned)rowc * ld_bytes + (unsigned)logical * 16u;
+    const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(lds + wbase * 16);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(src + 256 * sub), "s"(dst) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// bf16 hi + lo of a float32 pair: hi = RNE pack, lo = RNE pack of the remainders
+__device__ __forceinline__ void split_pack(float a, float b, unsigned int& hi, unsigned int& lo) {
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dW_v: 1024 threads = 16 waves as 8 (j) x 2 (k), block tile 256 (j) x 128 (k), wave tile 32 x 64, ONE block per CU.
+// Pooling roles: thread = (half = t >> 9, row = (t >> 4) & 31, 16-byte chunk = t & 15); a half pools MAXS / 2 of the head slots
+// (both halves fetch the row's x chunks: the second fetch is an L1/L2 hit).
+template <int M_, int MAXS>
+__global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p) {
+    using X = Tr<BF16>;
+    constexpr int RT = 2, CT = 4, SPH = MAXS / 2;
+    constexpr int NPL = HRB * MAXS * M_;                           // probabilities of a step (<= 1024: one per thread)
+    static_assert(NPL <= 1024 && MAXS % 2 == 0, "step shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int E = p.E, H = p.H;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    if (p.dq.w_k) dqp_rows<BF16>(p.dq, (int)blockIdx.x, (int)gridDim.x);      // side job: dq' for the finalize launch (aecf_common.h)
+
+    const unsigned int nK = (unsigned)(E / 128), nJt = (unsigned)(E / 256);
+    unsigned int split_u, tile_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)p.splits, nK * nJt, split_u, tile_u)) return;
+    const int kt_idx = (int)(tile_u % nK), jt_idx = (int)(tile_u / nK);
+    const int j0 = jt_idx * 256, k0 = kt_idx * 128;
+    const int split = (int)split_u;
+    const int64_t rbeg = (int64_t)split * p.rows_per_split;
+    const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
+
+    const int h_first = j0 / p.hd;
+    const int nslots = (j0 + 255) / p.hd - h_first + 1;
+
+    // LDS carve: lhs [2 buffers][hi, lo][2 sub-tiles] | pooled rhs [MAXS slots][hi, lo] | probabilities
+    char* ldsL = smem;
+    char* ldsR = smem + 8 * HR_TILE;
+    f32x2* pl = reinterpret_cast<f32x2*>(ldsR + 2 * MAXS * HR_TILE);          // [HRB][MAXS][M] (p, p) pairs
+
+    const int j0w = 32 * (w >> 1), k0w = 64 * (w & 1);
+    const int wslot = (j0 + j0w) / p.hd - h_first;
+    const bool do_cs = p.colsum != nullptr && kt_idx == 0 && k0w == 0;
+
+    const int q = r16 >> 2, pp = r16 & 3;
+    int tx[2][2];
+#pragma unroll
+    for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            tx[b1][hh] = 2048 * lg + 64 * q + 8 * (pp & 1) + 256 * hh + 16 * ((2 * b1 + (pp >> 1)) ^ (2 * (lg & 1) + hh));
+    const int a_org = (j0w >> 7) * HR_TILE + 512 * ((w >> 1) & 3);   // sub-tile, then lhs block 2 ((w >> 1) & 3) + rt
+    const int b_org = 1024 * (w & 1);
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 csacc[RT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) csacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* lhs_hi = reinterpret_cast<const char*>(p.lhs);
+    const char* lhs_lo = reinterpret_cast<const char*>(p.lhs_lo);
+    const char* rhs = reinterpret_cast<const char*>(p.rhs);
+    const unsigned int ldl = (unsigned)E * 2u;
+    const unsigned int ldr = (unsigned)M_ * (unsigned)E * 2u;
+
+    const int half = threadIdx.x >> 9, prow = (threadIdx.x >> 4) & 31, pc = threadIdx.x & 15;
+    const unsigned int prow_off = (unsigned)prow * ldr;
+    u32x4 Rb[M_];
+    float plr = 0.f;
+
+    auto issue_dma = [&](int64_t base, int buf) {
+        const int nvalid = (int)((rend - base) < HRB ? (rend - base) : HRB);
+        const int64_t off = base * (int64_t)ldl + (int64_t)j0 * 2;
+        dma_hr_images(lhs_hi + off, ldl, nvalid, ldsL + (4 * buf) * HR_TILE);
+        dma_hr_images(lhs_lo + off, ldl, nvalid, ldsL + (4 * buf + 2) * HR_TILE);
+    };
+    // probability (t, slot, m) of the step: thread idx = (t * MAXS + slot) * M + m
+    const int pt = threadIdx.x / (MAXS * M_), prem = threadIdx.x - pt * (MAXS * M_);
+    const int psl = prem / M_, pm = prem - psl * M_;
+    auto probs_on = [&](int64_t base) -> bool {
+        const int nvalid = (int)((rend - base) < HRB ? (rend - base) : HRB);
+        return (int)threadIdx.x < NPL && psl < nslots && pt < nvalid;
+    };
+    auto load_probs = [&](int64_t base) {
+        const float* pu = p.probs + (base * H + h_first) * M_;
+        const float* src = pu + (probs_on(base) ? (unsigned)(pt * H * M_ + psl * M_ + pm) : 0u);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(plr) : "v"(src) : "memory");
+    };
+    auto load_x = [&](int64_t base) {
+        const int nvalid = (int)((rend - base) < HRB ? (rend - base) : HRB);
+        const char* xu = rhs + base * (int64_t)ldr + (int64_t)k0 * 2;
+        const unsigned int last = (unsigned)(nvalid - 1) * ldr;
+        const unsigned int roff = (prow_off < last ? prow_off : last) + 16u * pc;
+#pragma unroll
+        for (int m = 0; m < M_; ++m) {
+            const char* xm = xu + (size_t)m * E * 2;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(Rb[m]) : "v"(roff), "s"(xm) : "memory");
+        }
+    };
+    auto mma_phase = [&](int cur, int nvalid_cur) {
+        const char* lt = ldsL + 4 * cur * HR_TILE + a_org;
+        const char* rt_tile = ldsR + 2 * wslot * HR_TILE + b_org;
+        u32x4 ah[RT], al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            ah[rt] = tr_frag(lt, tx[rt][0], tx[rt][1]);
+            al[rt] = tr_frag(lt + 2 * HR_TILE, tx[rt][0], tx[rt][1]);
+        }
+        if (do_cs) {                                      // row sums of do_hi + do_lo over the rows that exist
+            u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            if (nvalid_cur < HRB) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int kk = 8 * lg + 2 * d;
+                    ones[d] = (kk < nvalid_cur ? 0x3f80u : 0u) | (kk + 1 < nvalid_cur ? 0x3f800000u : 0u);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                csacc[rt] = X::mma(ah[rt], ones, csacc[rt]);
+                csacc[rt] = X::mma(al[rt], ones, csacc[rt]);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const char* bt = rt_tile + 512 * (ct >> 1);
+            const u32x4 bh = tr_frag(bt, tx[ct & 1][0], tx[ct & 1][1]);
+            const u32x4 bl = tr_frag(bt + HR_TILE, tx[ct & 1][0], tx[ct & 1][1]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                acc[rt][ct] = X::mma(ah[rt], bl, acc[rt][ct]);        // small terms first
+                acc[rt][ct] = X::mma(al[rt], bh, acc[rt][ct]);
+                acc[rt][ct] = X::mma(ah[rt], bh, acc[rt][ct]);
+            }
+        }
+    };
+
+    if (rbeg < rend) {
+        issue_dma(rbeg, 0);
+        load_probs(rbeg);
+        load_x(rbeg);
+    }
+    int cur = 0;
+    for (int64_t base = rbeg; base < rend; base += HRB, cur ^= 1) {
+        const bool more = base + HRB < rend;
+        const int nvalid_cur = (int)((rend - base) < HRB ? (rend - base) : HRB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's lhs tiles, x chunks and probabilities landed
+        asm volatile("" : "+v"(plr));
+        {
+            const float pv = probs_on(base) ? plr : 0.f;
+            if ((int)threadIdx.x < NPL) pl[threadIdx.x] = f32x2{pv, pv};
+        }
+#pragma unroll
+        for (int m = 0; m < M_; ++m) asm volatile("" : "+v"(Rb[m]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // MFMAs of the previous step done; lhs tiles + probabilities visible
+        if (more) {
+            issue_dma(base + HRB, cur ^ 1);
+            load_probs(base + HRB);
+        }
+        const f32x2* plc = pl + prow * (MAXS * M_) + half * SPH * M_;
+        f32x2 xv[M_][4];
+#pragma unroll
+        for (int m = 0; m < M_; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xv[m][i] = f32x2{__uint_as_float(Rb[m][i] << 16), __uint_as_float(Rb[m][i] & 0xffff0000u)};
+#pragma unroll
+        for (int m = 0; m < M_; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[m][i]));
+        if (more) load_x(base + HRB);                     // the chunk registers are free again: next step's chunk flies
+        const int woff = tr_off(prow, pc);
+#pragma unroll
+        for (int s2 = 0; s2 < SPH; ++s2) {
+            // (a slot the tile does not have carries zero probabilities: straight-line code, no test against nslots)
+            f32x2 pv[4];
+            const f32x2 p0 = plc[s2 * M_];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[i] = xv[0][i] * p0;
+#pragma unroll
+            for (int m = 1; m < M_; ++m) {
+                const f32x2 pm_ = plc[s2 * M_ + m];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pv[i] = __builtin_elementwise_fma(xv[m][i], pm_, pv[i]);
+            }
+            u32x4 oh, ol;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned int h_, l_;
+                split_pack(pv[i][0], pv[i][1], h_, l_);
+                oh[i] = h_;
+                ol[i] = l_;
+            }
+            char* dst = ldsR + 2 * (half * SPH + s2) * HR_TILE + woff;
+            *reinterpret_cast<u32x4*>(dst) = oh;
+            *reinterpret_cast<u32x4*>(dst + HR_TILE) = ol;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // pooled tiles visible
+        mma_phase(cur, nvalid_cur);
+    }
+
+    float* out = p.out + (int64_t)split * E * E;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(int64_t)(j0 + j0w + 16 * rt + 4 * lg + r) * E + k0 + k0w + 16 * ct + r16] = acc[rt][ct][r];
+    if (do_cs && r16 == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p.colsum[(int64_t)split * E + j0 + j0w + 16 * rt + 4 * lg + r] = csacc[rt][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dW_o: 512 threads = 8 waves as 4 (j) x 2 (k), block tile 128 x 128, wave tile 32 x 64; lhs = dy (one tile), rhs = o_hi and
+// o_lo (two tiles), all by LDS-DMA into two stages of 24 KB: three blocks per CU.
+__global__ __launch_bounds__(512, 3) void gemm_tn_hilo_plain_kernel(GemmTnArgs p) {
+    using X = Tr<BF16>;
+    constexpr int RT = 2, CT = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 stages][lhs | rhs hi | rhs lo]
+
+    const int E = p.E;
+    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
+    const unsigned int nK = (unsigned)(E / 128);
+    unsigned int split_u, tile_u;
+    if (!xcd_tile(blockIdx.x, (unsigned)p.splits, nK * nK, split_u, tile_u)) return;
+    const int kt_idx = (int)(tile_u % nK), jt_idx = (int)(tile_u / nK);
+    const int j0 = jt_idx * 128, k0 = kt_idx * 128;
+    const int split = (int)split_u;
+    const int64_t rbeg = (int64_t)split * p.rows_per_split;
+    const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
+
+    const int j0w = 32 * (w >> 1), k0w = 64 * (w & 1);
+    const bool do_cs = p.colsum != nullptr && kt_idx == 0 && k0w == 0;
+    const int q = r16 >> 2, pp = r16 & 3;
+    int tx[2][2];
+#pragma unroll
+    for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            tx[b1][hh] = 2048 * lg + 64 * q + 8 * (pp & 1) + 256 * hh + 16 * ((2 * b1 + (pp >> 1)) ^ (2 * (lg & 1) + hh));
+    const int a_org = 512 * (w >> 1);
+    const int b_org = 1024 * (w & 1);
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 csacc[RT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) csacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* lhs = reinterpret_cast<const char*>(p.lhs);
+    const char* rhs_hi = reinterpret_cast<const char*>(p.rhs);
+    const char* rhs_lo = reinterpret_cast<const char*>(p.rhs_lo);
+    const unsigned int ld = (unsigned)E * 2u;
+
+    auto issue_dma = [&](int64_t base, int buf) {
+        const int nvalid = (int)((rend - base) < HRB ? (rend - base) : HRB);
+        char* st = smem + 3 * buf * HR_TILE;
+        dma_hr_images(lhs + base * (int64_t)ld + (int64_t)j0 * 2, ld, nvalid, st);
+        dma_hr_images(rhs_hi + base * (int64_t)ld + (int64_t)k0 * 2, ld, nvalid, st + HR_TILE);
+        dma_hr_images(rhs_lo + base * (int64_t)ld + (int64_t)k0 * 2, ld, nvalid, st + 2 * HR_TILE);
+    };
+
+    if (rbeg < rend) issue_dma(rbeg, 0);
+    int cur = 0;
+    for (int64_t base = rbeg; base < rend; base += HRB, cur ^= 1) {
+        const bool more = base + HRB < rend;
+        const int nvalid_cur = (int)((rend - base) < HRB ? (rend - base) : HRB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's tiles landed (issued one step ago)
+        __builtin_amdgcn_s_barrier();                          // ... for every wave; MFMAs of the previous step done
+        char* st = smem + 3 * cur * HR_TILE;
+        if (nvalid_cur < HRB) {                                // ragged last step: zero the rhs rows that do not exist
+            for (int c = threadIdx.x; c < (HRB - nvalid_cur) * 16; c += 512) {
+                const int off = tr_off(nvalid_cur + (c >> 4), c & 15);
+                *reinterpret_cast<u32x4*>(st + HR_TILE + off) = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(st + 2 * HR_TILE + off) = u32x4{0u, 0u, 0u, 0u};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (more) issue_dma(base + HRB, cur ^ 1);
+        u32x4 a[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = tr_frag(st + a_org, tx[rt][0], tx[rt][1]);
+        if (do_cs) {
+            u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            if (nvalid_cur < HRB) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int kk = 8 * lg + 2 * d;
+                    ones[d] = (kk < nvalid_cur ? 0x3f80u : 0u) | (kk + 1 < nvalid_cur ? 0x3f800000u : 0u);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) csacc[rt] = X::mma(a[rt], ones, csacc[rt]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const char* bt = st + HR_TILE + b_org + 512 * (ct >> 1);
+            const u32x4 bh = tr_frag(bt, tx[ct & 1][0], tx[ct & 1][1]);
+            const u32x4 bl = tr_frag(bt + HR_TILE, tx[ct & 1][0], tx[ct & 1][1]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                acc[rt][ct] = X::mma(a[rt], bl, acc[rt][ct]);
+                acc[rt][ct] = X::mma(a[rt], bh, acc[rt][ct]);
+            }
+        }
+    }
+
+    float* out = p.out + (int64_t)split * E * E;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(int64_t)(j0 + j0w + 16 * rt + 4 * lg + r) * E + k0 + k0w + 16 * ct + r16] = acc[rt][ct][r];
+    if (do_cs && r16 == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p.colsum[(int64_t)split * E + j0 + j0w + 16 * rt + 4 * lg + r] = csacc[rt][r];
+    }
+}
+
+template <int M_, int MAXS>
+void launch_hilo_wide(const GemmTnArgs& a, hipStream_t s) {
+    const size_t smem = (size_t)(8 + 2 * MAXS) * HR_TILE + (size_t)HRB * MAXS * M_ * 2 * sizeof(float);
+    dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)((a.E / 128) * (a.E / 256)))), block(1024);
+    auto kern = gemm_tn_hilo_wide_kernel<M_, MAXS>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a);
+}
+
+int hilo_slots_256(int E, int hd) {               // head slots of the widest aligned 256-row window, rounded up to even
+    int mx = 1;
+    for (int j0 = 0; j0 < E; j0 += 256) {
+        const int n = (j0 + 255) / hd - j0 / hd + 1;
+        if (n > mx) mx = n;
+    }
+    return mx <= 2 ? 2 : (mx <= 4 ? 4 : 0);
+}
+
+}  // namespace
+
+// shapes of the one-launch hi + lo products: E a multiple of 256 (256-row j tiles, 128-column k tiles), at most 4 head slots
+// per j tile, M <= 3 (the 128-VGPR budget of the 1024-thread block), rows_per_split a multiple of 32
+bool gemm_tn_hilo_supported(const GemmTnArgs& a) {
+    if (a.E % 256 != 0 || a.M < 1 || a.M > 3 || (a.Ej > 0 && a.Ej != a.E) || a.rows_per_split % HRB != 0) return false;
+    return !a.pooled || hilo_slots_256(a.E, a.hd) != 0;
+}
+
+void launch_gemm_tn_hilo(const GemmTnArgs& a, hipStream_t s) {
+    if (!a.pooled) {
+        const size_t smem = (size_t)6 * HR_TILE;
+        dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)((a.E / 128) * (a.E / 128)))), block(512);
+        gemm_tn_hilo_plain_kernel<<<grid, block, smem, s>>>(a);
+        return;
+    }
+    const bool two = hilo_slots_256(a.E, a.hd) == 2;
+    switch (a.M) {
+        case 1: if (two) launch_hilo_wide<1, 2>(a, s); else launch_hilo_wide<1, 4>(a, s); return;
+        case 2: if (two) launch_hilo_wide<2, 2>(a, s); else launch_hilo_wide<2, 4>(a, s); return;
+        default: if (two) launch_hilo_wide<3, 2>(a, s); else launch_hilo_wide<3, 4>(a, s); return;
+    }
+}
+
+}  // namespace aecf

@@ -165,10 +165,15 @@ struct GemmTnArgs {
     int pooled;
     int parts = 0;            // pooled: 0 = main product + u, 1 = main product only, 2 = u only (separate stage timing)
     DqpJob dq;                // bf16 transposed-read kernels only: side job of the launch (aecf_common.h); w_k == null: off
-    int pool_lo = 0;          // pooled bf16 kernels: feed the MFMA the LOW part of the pooled rows, bf16(P - float(bf16(P)))
+    // AECF_HILO_GRADS (aecf_gemm_tn_hilo.hip): the low parts of the operands that are derived values -- lhs_lo = do_lo (pooled
+    // product; the pooled rows are split where they are formed), rhs_lo = o_lo (plain product; its lhs dy is an exact input)
+    const void* lhs_lo = nullptr;
+    const void* rhs_lo = nullptr;
 };
 void launch_gemm_tn(int dtype, const GemmTnArgs& a, hipStream_t s);
 void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s);   // bf16, ds_read_b64_tr_b16 form (main product only)
+bool gemm_tn_hilo_supported(const GemmTnArgs& a);             // hi + lo operand pairs in ONE launch (lhs_lo / rhs_lo set)
+void launch_gemm_tn_hilo(const GemmTnArgs& a, hipStream_t s);
 bool u_mfma_supported(const GemmTnArgs& a);                    // u = ds^T x on the matrix pipe (bf16, H <= 8, E % 128 == 0)
 void launch_u_mfma(const GemmTnArgs& a, hipStream_t s);
 
@@ -180,6 +185,7 @@ struct ReduceSegs {
     int64_t n[N];
     int splits[N];
     int dst_bf16[N];      // 1: dst is bf16 (one rounding of the float32 sum)
+    float scale[N] = {1.f, 1.f, 1.f, 1.f, 1.f};   // the sum is multiplied by this before it is stored (aecf_pool_bwd_args.grad_scale)
 };
 // tokens of the debug knob AECF_DEBUG (aecf_capi.hip)
 bool env_no_ws();
@@ -204,6 +210,7 @@ struct FinalizeArgs {
     int E, H, hd;
     float scale;
     int grad_bf16;
+    float gscale = 1.f;   // every gradient this launch writes is multiplied by it (aecf_pool_bwd_args.grad_scale)
 };
 void launch_dqp(int dtype, const DqpJob& q, hipStream_t s);        // dq' as its own small launch (shapes without the side job)
 void launch_finalize_all(int dtype, const FinalizeArgs& a, const ReduceSegs& r, hipStream_t s);   // slab reduction + the above, ONE launch

@@ -10,14 +10,19 @@ counterpart; it is what BASELINE.json's north_star asks for around the fused ker
   the 4E^2+5E values travel as a single collective (a few MB: latency-bound on xGMI, so one big
   message, not one per tensor), (2) an all-gather of fused embeddings for cross-batch contrastive
   negatives whose backward is a reduce-scatter of the gradient, (3) scalar means of the logged statistics.
-* mask RNG: every rank slices the SAME global uniform tensor (``global_uniforms`` + ``shard_batch``) and hands its rows
-  to the pool through the public ``uniforms=`` argument of ``MultimodalAttentionPool.forward`` /
-  ``CurriculumMasking.forward``, so N-rank masks equal 1-rank masks bit for bit.
+* mask RNG: every rank seeds its device generator alike and names its rows of the global batch
+  (``pool(..., batch_shard=(first_row, global_batch))``): the statistics kernel evaluates the rank's elements of ONE global
+  draw, so N-rank masks equal 1-rank masks bit for bit with no uniforms tensor and no launch (a recorded draw still goes
+  through the public ``uniforms=`` argument: ``global_uniforms`` + ``shard_batch``).
 * replicas are made identical by ``broadcast_parameters``; gradient averaging is unweighted, uneven shards scale their
   local loss by ``shard_loss_scale``.
+* ``attach(pool)`` makes a pool module data-parallel: its backward folds 1 / world into the parameter gradients as it stores
+  them (the average is then ONE sum all-reduce, no divide launch) and keeps float32 sums for bf16 parameters.  Per module,
+  explicit -- nothing here flips a process-wide switch.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, List, Optional
 
 import torch
@@ -130,7 +135,6 @@ def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=Non
     _, world = world_info(group)
     if world == 1:
         return
-    keep_f32_grad_sums(True)                 # (a data-parallel run: bf16 gradients are rounded once, after the collective)
     by_dtype = {}
     for p in params:
         by_dtype.setdefault(p.dtype, []).append(p)
@@ -144,16 +148,65 @@ def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=Non
                 off += p.numel()
 
 
-def keep_f32_grad_sums(on: bool = True) -> None:
-    """Reduced-precision parameters (bf16): have the fused backward keep its float32 batch sums next to the bf16 gradients it
-    hands autograd, so that ``all_reduce_grads`` / ``GradOverlap`` move and average the float32 values and round the MEAN once
-    into ``p.grad`` -- an N-rank gradient then differs from the one-rank gradient by float32 summation order only, not by a
-    bf16 rounding per rank (up to one bf16 ulp, 7.8e-3 of an element).  Costs one cast kernel per backward.  Turned on by
-    ``broadcast_parameters`` when world > 1."""
+# pool modules made data-parallel by attach(): parameter id -> weak reference to the module (all_reduce_grads / GradOverlap find
+# the module's DpState through the parameters they are handed; a module that is gone drops out by itself)
+_attached = {}
+
+
+def attach(pool, group=None, average: bool = True, keep_f32: bool = True, defer_rounding: bool = False, world: Optional[int] = None):
+    """Make ONE ``MultimodalAttentionPool`` data-parallel (explicit, per module).  Its fused backward then
+    (a) multiplies the five parameter gradients by 1 / world as it stores them (``average``; aecf_pool_bwd_args.grad_scale),
+    so ``all_reduce_grads`` / ``GradOverlap`` issue ONE sum collective with no divide launch around it, and
+    (b) with bf16 parameters (``keep_f32``) writes its float32 batch sums: the collective moves and adds THOSE and the bf16
+    gradient is rounded ONCE from the mean -- an N-rank gradient then differs from the one-rank gradient by float32 summation
+    order only.  ``defer_rounding``: the bf16 ``p.grad`` tensors stay UNINITIALISED between the backward and the collective
+    (no cast launch; the caller promises to call ``all_reduce_grads`` / ``GradOverlap.finish`` before reading them).
+    Until the collective has run, ``p.grad`` holds this rank's gradient divided by world.  ``world`` overrides the group's
+    size (rehearsals).  ``detach(pool)`` undoes it.  Returns the module's ``layer.DpState``."""
     from . import layer
-    layer._keep_f32_sums = bool(on)
-    if not on:
-        layer._f32_sums.clear()
+    if world is None:
+        _, world = world_info(group)
+    st = layer.DpState(world, (1.0 / world) if (average and world > 1) else 1.0, keep_f32, defer_rounding)
+    pool._options().dp = st
+    ref = weakref.ref(pool)
+    for p in pool.parameters():
+        _attached[id(p)] = ref
+    return st
+
+
+def detach(pool) -> None:
+    pool._options().dp = None
+    for p in pool.parameters():
+        _attached.pop(id(p), None)
+
+
+def _states_of(params) -> list:
+    """DpStates of the attached pool modules that own any of ``params`` (each once)."""
+    out, seen = [], set()
+    for p in params:
+        ref = _attached.get(id(p))
+        pool = None if ref is None else ref()
+        if pool is None:
+            continue
+        st = pool._options().dp
+        if st is not None and id(st) not in seen:
+            seen.add(id(st))
+            out.append(st)
+    return out
+
+
+def _all_states() -> list:
+    out, seen = [], set()
+    for key, ref in list(_attached.items()):
+        pool = ref()
+        if pool is None:
+            _attached.pop(key, None)
+            continue
+        st = pool._options().dp
+        if st is not None and id(st) not in seen:
+            seen.add(id(st))
+            out.append(st)
+    return out
 
 
 def shard_loss_scale(b_local: int, b_global: int, world: int) -> float:
@@ -186,7 +239,8 @@ def flat_grad_alias(params: Iterable[torch.nn.Parameter]) -> Optional[torch.Tens
     return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(st, spans[0][0], (off - spans[0][0],))
 
 
-def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = True, fp32: Optional[bool] = None):
+def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = True, fp32: Optional[bool] = None,
+                     rehearse: bool = False):
     """One collective for the gradients of ``params``: in place over their shared allocation when they alias one
     (see flat_grad_alias), else through a temporary flat copy.  Averages inside the collective (ReduceOp.AVG) when
     probe_avg_support found the backend takes it, else divides and sums.  The average is unweighted: with uneven
@@ -195,21 +249,30 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
     bf16 rounds at every hop, eight ranks' worth of it is the difference between 2e-2 and the single rounding the one-rank
     step has (each rank's own rounding of its float32 batch sums to its bf16 ``p.grad`` has already happened and stays; at
     4 E^2 + 5 E elements the float32 transport is 4 MB at d = 512, a latency-bound collective either way).  ``fp32=False``
-    keeps the gradients' own dtype on the wire."""
+    keeps the gradients' own dtype on the wire.  ``rehearse``: issue the collective even on a ONE-rank group (bench.py
+    --force-dp: the RCCL call, and its capture into a HIP graph, on a one-GPU box)."""
     params = [p for p in params if p.requires_grad and p.grad is not None]
     _, world = world_info(group)
-    if world == 1 or not params:
+    if (world == 1 and not (rehearse and dist.is_initialized())) or not params:
         return
     flat = flat_grad_alias(params)
     reduced = any(p.grad.dtype in (torch.bfloat16, torch.float16) for p in params)
     if fp32 is None:
         fp32 = reduced
+    # what the attached module's backward left about this very run: its float32 sums (bf16 parameters) and whether the
+    # gradients already carry the factor 1 / world (attach: grad_scale)
+    wide, prescaled = None, False
+    for st in _states_of(params):
+        w_, pre_ = st.take(flat)
+        if w_ is not None or pre_:
+            wide, prescaled = w_, pre_
+    if prescaled and not average:
+        raise RuntimeError("all_reduce_grads(average=False) on gradients an attached pool already divided by world")
+    divide = average and not prescaled
     if fp32 and reduced:
-        from . import layer
-        wide = layer.take_f32_sums(flat)              # the backward's own float32 sums, where it left them (keep_f32_grad_sums)
         if wide is None:
             wide = flat.float() if flat is not None else torch.cat([p.grad.reshape(-1).float() for p in params])
-        if average:
+        if divide:
             wide.div_(world)                          # (before the sum, as GradOverlap does: the two paths stay bit-equal)
         dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
         if flat is not None:
@@ -224,10 +287,10 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
     copied = flat is None
     if copied:
         flat = torch.cat([p.grad.reshape(-1).to(params[0].grad.dtype) for p in params])
-    if average and _avg_support.get((dist.get_backend(group), flat.dtype), False):
+    if divide and _avg_support.get((dist.get_backend(group), flat.dtype), False):
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
     else:
-        if average:
+        if divide:
             flat.div_(world)                          # pre-divide: the sum of bf16 values then stays in range
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if copied:
@@ -242,7 +305,7 @@ class GradOverlap:
     """EXPERIMENTAL (never run over RCCL on real multi-GPU hardware by this build: only the gloo rehearsal on one GPU).
     Runs the all-reduce of the fusion layer's parameter gradients BEHIND the input-gradient kernel of its backward.
 
-    With this object installed (as ``layer._param_grads_hook``) the backward computes dx last and the library announces
+    With this object installed (on the ``DpState`` of the attached pool modules: ``dp.attach``) the backward computes dx last and the library announces
     the moment the five parameter gradients are final with a HIP event (aecf_pool_bwd_args.param_grads_event); a side
     stream waits for that event and issues ONE collective there, in place on the gradient allocation, while the dx
     kernel runs on the caller's stream.  ``finish`` makes the current stream wait for it and reduces, the plain way, any
@@ -268,35 +331,44 @@ class GradOverlap:
         self.params = None if params is None else list(params)
         self.stream = None
         self.pending = []                                   # (flat, work) of every collective issued since the last finish
+        self._hooked = []                                   # DpStates this region installed itself on
 
     def __enter__(self):
-        from . import layer
         _, world = world_info(self.group)
         accumulating = self.params is not None and any(p.grad is not None for p in self.params)
+        self._hooked = []
         if world > 1 and not accumulating:
-            layer._param_grads_hook = self
+            # the hook lives on the attached pool modules (dp.attach) whose parameters this region covers -- all attached
+            # modules when no parameter list was given; a pool that was never attached is reduced by finish() the plain way
+            for st in (_states_of(self.params) if self.params is not None else _all_states()):
+                st.hook = self
+                self._hooked.append(st)
         return self
 
     def __exit__(self, *exc):
-        from . import layer
-        layer._param_grads_hook = None
+        for st in self._hooked:
+            st.hook = None
+        self._hooked = []
         return False
 
-    def _reduce(self, flat, async_op):
+    def _reduce(self, flat, async_op, divide=True):
         _, world = world_info(self.group)
-        if self.average and _avg_support.get((dist.get_backend(self.group), flat.dtype), False):
+        divide = divide and self.average
+        if divide and _avg_support.get((dist.get_backend(self.group), flat.dtype), False):
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
-        if self.average:
+        if divide:
             flat.div_(world)
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
-    def __call__(self, flat: torch.Tensor, event, flat32: Optional[torch.Tensor] = None) -> None:
+    def __call__(self, flat: torch.Tensor, event, flat32: Optional[torch.Tensor] = None, state=None) -> None:
         # reduced-precision gradients whose float32 sums the backward kept: the collective runs on THOSE and finish() rounds the
-        # mean into `flat` (the allocation autograd holds) once
+        # mean into `flat` (the allocation autograd holds, left uninitialised by the backward) once
+        prescaled = False
+        if state is not None and state.last is not None:
+            prescaled = bool(state.last[3])
+            state.last = None                                # consumed here, not by all_reduce_grads
         low = None
         if flat32 is not None:
-            from . import layer
-            layer._f32_sums.pop(flat.untyped_storage().data_ptr(), None)     # consumed here, not by all_reduce_grads
             low, flat = flat, flat32
         if self.pending:
             # A SECOND fused backward inside one region (two pool applications, or two backward() calls): autograd is about
@@ -311,7 +383,7 @@ class GradOverlap:
                     low_.copy_(wide_)
             self.pending = [(a_, None, None) for a_, _, _ in self.pending]
             torch.cuda.current_stream().wait_stream(self.stream)
-            self._reduce(flat, async_op=False)
+            self._reduce(flat, async_op=False, divide=not prescaled)
             if low is not None:
                 low.copy_(flat)
             self.pending.append((flat if low is None else low, None, None))
@@ -320,8 +392,10 @@ class GradOverlap:
             self.stream = torch.cuda.Stream(device=flat.device)
         self.stream.wait_event(event)                       # the gradients are final once the library's event has fired
         with torch.cuda.stream(self.stream):
-            work = self._reduce(flat, async_op=True)
+            work = self._reduce(flat, async_op=True, divide=not prescaled)
         flat.record_stream(self.stream)
+        if low is not None:
+            low.record_stream(self.stream)
         self.pending.append((flat if low is None else low, work, None if low is None else flat))
 
     def finish(self, params: Iterable[torch.nn.Parameter]) -> None:

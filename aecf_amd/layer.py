@@ -58,28 +58,67 @@ def _draw_uniforms(shape, device, uniforms: Optional[torch.Tensor] = None,
     return torch.rand(shape, dtype=torch.float32, device=device, generator=generator)
 
 
-def _philox_draw(n: int, device: torch.device, generator: Optional[torch.Generator] = None):
+def _philox_draw(n: int, device: torch.device, generator: Optional[torch.Generator] = None, element0: int = 0):
     """The generator call ``torch.rand(n, device=device, generator=generator)`` WITHOUT making it: returns
-    ``(seed, offset, threads)`` -- the generator's state before the call and the thread count of torch's launch
+    ``(seed, offset, threads, element0)`` -- the generator's state before the call and the thread count of torch's launch
     (ATen/native/cuda/DistributionTemplates.h: blocks of 256, grid = min(ceil(n / 256), CUs * max_threads_per_CU / 256)) --
     and advances the generator by what that call consumes (4 per 4 * threads elements, one iteration here).  The statistics
     kernel evaluates the same Philox4x32-10 stream element by element (AECF_DRAW_UNIFORMS, include/aecf_hip.h), so the masks are
     those of the tensor path bit for bit (``tests/test_pool_gpu.py::test_in_kernel_uniforms_equal_torch_rand``).
+    ``element0``: the caller's rows start at this element of the n-element draw (a data-parallel shard, ABI v9).
     Returns None where the offset cannot be read on the host: while the stream is being captured into a graph (a replay
-    must see a fresh offset: torch's graph-safe generator state does that for ``torch.rand``) or for a non-device generator."""
+    must see a fresh offset: torch's graph-safe generator state does that for ``torch.rand``), for a non-device generator, or
+    when this torch build's ``torch.rand`` does not have the launch geometry written down here (checked once per device)."""
     if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
         return None
     index = device.index if device.index is not None else torch.cuda.current_device()
     gen = generator if generator is not None else torch.cuda.default_generators[index]
     if gen.device.type != "cuda":
         return None
+    if not _draw_geometry_ok(index):
+        return None
+    seed, offset, threads, increment = _philox_geometry(n, index, gen)
+    gen.set_offset(offset + increment)
+    return seed, offset, threads, int(element0)
+
+
+def _philox_geometry(n: int, index: int, gen: torch.Generator):
     props = _device_props(index)
     blocks = min((n + 255) // 256, props[0] * (props[1] // 256))
     threads = 256 * blocks
     increment = ((n - 1) // (threads * 4) + 1) * 4
-    seed, offset = gen.initial_seed(), gen.get_offset()
-    gen.set_offset(offset + increment)
-    return int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset), int(threads)
+    return int(gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF, int(gen.get_offset()), int(threads), int(increment)
+
+
+_geometry_ok: Dict[int, bool] = {}
+
+
+def _draw_geometry_ok(index: int) -> bool:
+    """ATen's launch geometry of ``torch.rand`` (block 256, unroll 4, the grid cap, the offset increment) is private to torch;
+    the in-kernel draw is only used where it reproduces THIS torch build's tensor: once per device, a draw below and one beyond
+    the grid cap are made both ways from a scratch generator and compared (values and generator advance).  A mismatch falls
+    back to the tensor path for the life of the process (one ``torch.rand`` launch more per step; the masks stay valid)."""
+    ok = _geometry_ok.get(index)
+    if ok is None:
+        ok = True
+        try:
+            lib = _lib.load()
+            dev = torch.device("cuda", index)
+            props = _device_props(index)
+            for n in (1000, 256 * props[0] * (props[1] // 256) * 4 + 333):
+                gen = torch.Generator(device=dev).manual_seed(0x5EED + n)
+                torch.rand(8, device=dev, generator=gen)                      # a non-zero offset to start from
+                seed, offset, threads, increment = _philox_geometry(n, index, gen)
+                want = torch.rand(n, device=dev, generator=gen)
+                got = torch.empty(n, dtype=torch.float32, device=dev)
+                _lib.check(lib.aecf_philox_uniforms(n, seed, offset, threads, 0, _ptr(got), _stream()), "aecf_philox_uniforms")
+                if gen.get_offset() != offset + increment or not torch.equal(got, want):
+                    ok = False
+                    break
+        except Exception:                                                     # noqa: BLE001 -- any surprise: tensor path
+            ok = False
+        _geometry_ok[index] = ok
+    return ok
 
 
 _props_cache: Dict[int, Tuple[int, int]] = {}
@@ -94,13 +133,59 @@ def _device_props(index: int) -> Tuple[int, int]:
     return p
 
 
-# AECF_HILO_GRADS (include/aecf_hip.h): the weight-gradient products of the fused backward on bf16 hi + lo operand pairs, so
-# that float32-stored parameter gradients are float32-accurate (a verification / high-accuracy mode: three more launches of
-# the batch-reduction kernels per step).  Off by default; shapes the flag is not built for run the default path.
-_HILO_GRADS = False
+class DpState:
+    """Data-parallel state of ONE pool module (``aecf_amd.dp.attach`` makes it; nothing here is process-global).
 
-# in-kernel draw of the curriculum mask's uniforms (no torch.rand launch, no [B,M] tensor); tests switch it off to compare
-_DRAW_IN_KERNEL = True
+    ``grad_scale``: factor the backward folds into the five parameter gradients as it stores them (1 / world: the gradient
+    average is then ONE sum all-reduce, no divide launch).  ``keep_f32``: bf16 parameters -- the backward writes its float32
+    batch sums, the collective averages THOSE and the bf16 gradient is rounded once from the mean.  ``defer_rounding``: with
+    ``keep_f32`` the bf16 tensors autograd receives stay UNINITIALISED until ``dp.all_reduce_grads`` / ``GradOverlap.finish``
+    writes the rounded mean into them (no cast launch in the backward; reading ``p.grad`` before the collective is an error).
+    ``hook``: a ``dp.GradOverlap`` while one is active.  ``last``: (flat, flat32, version, prescaled) of the last backward."""
+    __slots__ = ("world", "grad_scale", "keep_f32", "defer_rounding", "hook", "last")
+
+    def __init__(self, world: int = 1, grad_scale: float = 1.0, keep_f32: bool = True, defer_rounding: bool = False):
+        self.world, self.grad_scale, self.keep_f32, self.defer_rounding = int(world), float(grad_scale), bool(keep_f32), bool(defer_rounding)
+        self.hook = None
+        self.last = None
+
+    def take(self, flat: Optional[torch.Tensor]):
+        """(float32 sums or None, prescaled) behind the gradient run ``flat`` (as dp.flat_grad_alias returns it) if the last
+        fused backward of this module wrote that run and nothing has written to it since; consumed by the call."""
+        hit, self.last = self.last, None
+        if hit is None or flat is None:
+            return None, False
+        mine, wide, version, prescaled = hit
+        if (mine._version != version or mine.data_ptr() != flat.data_ptr() or mine.numel() != flat.numel()
+                or mine.dtype != flat.dtype):
+            return None, False
+        return wide, prescaled
+
+
+class PoolOptions:
+    """Per-module switches of the fused path (``MultimodalAttentionPool.options``); tests and bench.py set them on the module
+    they drive, nothing is process-global.
+
+    ``hilo_grads``: the weight-gradient products of the backward on bf16 hi + lo operand pairs (AECF_HILO_GRADS,
+    include/aecf_hip.h) -- None (default) = whenever the parameter gradients are float32-STORED under bf16 activations (float32
+    master weights: there the operand roundings of the default products are visible, 1.3e-3 .. 2.3e-3 of fp32 math at the
+    headline shape; a bf16-stored gradient hides them behind its own rounding), True / False = forced.  Shapes the flag is not
+    built for run the default products.
+    ``draw_in_kernel``: the curriculum mask's uniforms are drawn by the statistics kernel (no torch.rand launch, no [B, M]
+    tensor).  ``share_prep``: the forward's preparation launch also produces what the backward derives from the parameters
+    alone.  ``stage_events``: (forward, backward) arrays of hipEvent_t the library records at its stage boundaries (bench.py).
+    ``dp``: DpState of a data-parallel run."""
+    __slots__ = ("hilo_grads", "draw_in_kernel", "share_prep", "stage_events", "dp")
+
+    def __init__(self):
+        self.hilo_grads: Optional[bool] = None
+        self.draw_in_kernel = True
+        self.share_prep = True
+        self.stage_events = None
+        self.dp: Optional[DpState] = None
+
+
+_DEFAULT_OPTIONS = PoolOptions()           # direct users of _PoolFunction.apply (never modified)
 
 
 def _require_device(t: torch.Tensor, what: str) -> None:
@@ -112,38 +197,6 @@ def _require_device(t: torch.Tensor, what: str) -> None:
 # ----------------------------------------------------------------------------------------------
 # autograd bridges (one per C-ABI operator)
 # ----------------------------------------------------------------------------------------------
-# forward prepares the backward's parameter-only operands too (aecf_pool_fwd_args.saved_prep); tests switch it off to
-# compare against the backward's own preparation stage
-_SHARE_PREP = True
-
-# Data-parallel overlap hook (aecf_amd/dp.py: GradOverlap): when set, the backward asks the library to compute the input
-# gradient last and to announce (a HIP event) the moment the five parameter gradients are final, and hands the hook that
-# event together with the allocation that holds them, so that their all-reduce runs behind the dx kernel.  None = off.
-_param_grads_hook = None
-
-# Data parallel with reduced-precision parameters (bf16): the backward's float32 batch sums are rounded ONCE, after the
-# collective, instead of once per rank before it and once more after (which puts a two-rank gradient up to a bf16 ulp, 7.8e-3
-# of the element, away from the one-rank gradient).  With the switch on (dp.broadcast_parameters turns it on when world > 1;
-# dp.keep_f32_grad_sums) the backward asks the library for float32 gradients, hands autograd their bf16 rounding as usual and
-# leaves the float32 run here, keyed by the bf16 allocation, for dp.all_reduce_grads / dp.GradOverlap to reduce and round.
-_keep_f32_sums = False
-_f32_sums: Dict[int, Tuple[torch.Tensor, torch.Tensor, int]] = {}     # bf16 storage pointer -> (flat, flat32, flat._version)
-
-
-def take_f32_sums(flat: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """The float32 sums behind the reduced-precision gradient run ``flat`` (as dp.flat_grad_alias returns it), if the last
-    fused backward left them and nothing has written to that run since; consumed by the call."""
-    if flat is None or not _f32_sums:
-        return None
-    hit = _f32_sums.pop(flat.untyped_storage().data_ptr(), None)
-    if hit is None:
-        return None
-    mine, wide, version = hit
-    if (mine._version != version or mine.data_ptr() != flat.data_ptr() or mine.numel() != flat.numel()
-            or mine.dtype != flat.dtype):
-        return None
-    return wide
-
 # what the library answers per call shape (status of aecf_pool_check, workspace sizes, whether the backward wants V):
 # pure functions of the description, asked once per shape instead of on every call (each ctypes round trip is ~1-2 us of a
 # host-bound step at small batches)
@@ -156,7 +209,8 @@ def _pool_facts(lib, desc, key):
         ref = ctypes.byref(desc)
         status = lib.aecf_pool_check(ref)
         f = (status,) if status != 0 else (0, lib.aecf_pool_fwd_workspace_bytes(ref), lib.aecf_pool_bwd_workspace_bytes(ref),
-                                           lib.aecf_pool_prep_bytes(ref), bool(lib.aecf_pool_wants_saved_v(ref)))
+                                           lib.aecf_pool_prep_bytes(ref), bool(lib.aecf_pool_wants_saved_v(ref)),
+                                           lib.aecf_pool_hilo_bwd_workspace_bytes(ref))
         if len(_shape_facts) > 256:
             _shape_facts.clear()
         _shape_facts[key] = f
@@ -170,8 +224,10 @@ class _PoolFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, q, w_in, b_in, w_out, b_out, kpm, uniforms, num_heads, mask_mode, min_active,
-                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None, casts=None, side=None, philox=None):
+                base_mask_prob, entropy_target, eps, f32_info=False, target_value=None, casts=None, side=None, philox=None,
+                opts=None):
         lib = _lib.load()
+        opts = _DEFAULT_OPTIONS if opts is None else opts
         ctx.set_materialize_grads(False)       # unused outputs arrive as None, not as zero tensors (fill + cast launches)
         B, M, E = x.shape
         dt = x.dtype
@@ -179,7 +235,7 @@ class _PoolFunction(torch.autograd.Function):
                              entropy_target, eps)
         facts = _pool_facts(lib, desc, (B, M, E, num_heads, dt, mask_mode))
         _lib.check(facts[0], "aecf_pool_check")
-        _, fwd_ws_bytes, bwd_ws_bytes, prep_bytes, wants_v = facts
+        _, fwd_ws_bytes, bwd_ws_bytes, prep_bytes, wants_v, hilo_bytes = facts
         xc = x.contiguous()
         qc = q.detach().reshape(E).to(dt).contiguous()
         if casts is not None:                  # activation-dtype copies of master weights, cached by the module
@@ -198,7 +254,7 @@ class _PoolFunction(torch.autograd.Function):
         need_bwd = any(t is not None and t.requires_grad for t in (x, q, w_in, b_in, w_out, b_out))
         saved_v = torch.empty(B, M, E, dtype=dt, device=dev) if (need_bwd and wants_v) else None
         # what the backward derives from the parameters alone is produced by the forward's preparation launch
-        saved_prep = torch.empty(prep_bytes, dtype=torch.uint8, device=dev) if (need_bwd and _SHARE_PREP) else None
+        saved_prep = torch.empty(prep_bytes, dtype=torch.uint8, device=dev) if (need_bwd and opts.share_prep) else None
         if mask_mode != 0:
             masked_w = torch.empty(B, M, dtype=torch.float32, device=dev)
             entropy = torch.empty(B, dtype=torch.float32, device=dev)
@@ -229,14 +285,16 @@ class _PoolFunction(torch.autograd.Function):
         flags = 0
         saved_o_lo = None
         hilo_ws = 0
-        if _HILO_GRADS and need_bwd and dt == torch.bfloat16:
-            hilo_ws = lib.aecf_pool_hilo_bwd_workspace_bytes(ctypes.byref(desc))
-            if hilo_ws > 0:
-                saved_o_lo = torch.empty(B, E, dtype=dt, device=dev)
-                flags |= _lib.AECF_HILO_GRADS
-        ph_seed = ph_off = ph_threads = 0
+        hilo = opts.hilo_grads
+        if hilo is None:                           # automatic: the parameter gradients will be STORED in float32 (layer.PoolOptions)
+            hilo = any(t is not None and t.dtype != dt for t in (q, w_in, b_in, w_out, b_out))
+        if hilo and need_bwd and dt == torch.bfloat16 and hilo_bytes > 0:
+            hilo_ws = hilo_bytes
+            saved_o_lo = torch.empty(B, E, dtype=dt, device=dev)
+            flags |= _lib.AECF_HILO_GRADS
+        ph_seed = ph_off = ph_threads = ph_elem0 = 0
         if philox is not None and mask_mode == 1 and uniforms is None:
-            ph_seed, ph_off, ph_threads = philox
+            ph_seed, ph_off, ph_threads, ph_elem0 = philox
             flags |= _lib.AECF_DRAW_UNIFORMS
         ws_bytes = fwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -244,13 +302,14 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(b_out_c), _ptr(kpm),
             _ptr(uniforms), _ptr(y), _ptr(attn_w), _ptr(masked_w), _ptr(entropy), _ptr(mask_rate),
             _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(ws), ws_bytes,
-            None if _lib.stage_events_fwd is None else ctypes.addressof(_lib.stage_events_fwd),
+            None if opts.stage_events is None else ctypes.addressof(opts.stage_events[0]),
             _ptr(i_attn_w), _ptr(i_masked_w), _ptr(i_entropy), _ptr(i_mask_rate), _ptr(saved_prep),
             _ptr(i_target), 0.0 if target_value is None else float(target_value), flags, _ptr(ent_partial),
-            ph_seed, ph_off, ph_threads, _ptr(ent_loss), _ptr(saved_o_lo))
+            ph_seed, ph_off, ph_threads, _ptr(ent_loss), _ptr(saved_o_lo), ph_elem0)
         _lib.check(lib.aecf_pool_forward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_forward")
         ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep, saved_o_lo)
         ctx.desc = desc
+        ctx.opts = opts
         ctx.bwd_ws_bytes = hilo_ws if saved_o_lo is not None else bwd_ws_bytes
         ctx.q_shape = q.shape
         ctx.param_dtypes = (q.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
@@ -286,14 +345,17 @@ class _PoolFunction(torch.autograd.Function):
         gdt = dt if all(p is None or p == dt for p in ctx.param_dtypes) else torch.float32
         # one allocation for the five of them: autograd keeps these tensors as p.grad without copying, so a data-parallel
         # caller can all-reduce the whole run in place with a single collective (aecf_amd/dp.py: all_reduce_grads)
-        keep32 = _keep_f32_sums and gdt != torch.float32
+        opts = ctx.opts
+        dp_ = opts.dp
+        keep32 = dp_ is not None and dp_.keep_f32 and gdt != torch.float32
+        gscale = dp_.grad_scale if dp_ is not None else 1.0          # (1 / world: the average is then ONE sum all-reduce)
         out_dt = torch.float32 if keep32 else gdt                 # what the library writes
         flat = torch.empty(4 * E * E + 5 * E, dtype=out_dt, device=dev)
         dquery, dw_in, db_in, dw_out, db_out = flat.split([E, 3 * E * E, 3 * E, E * E, E])
         dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
         ws_bytes = ctx.bwd_ws_bytes
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        hook, early = _param_grads_hook, None
+        hook, early = (None if dp_ is None else dp_.hook), None
         if hook is not None and any(p is not None and p != gdt for p in ctx.param_dtypes):
             hook = None        # the gradients handed to autograd would be cast COPIES of `flat`: nothing to reduce in place
         if hook is not None:
@@ -303,23 +365,25 @@ class _PoolFunction(torch.autograd.Function):
             _ptr(xc), _ptr(qc), _ptr(w_in_c), _ptr(b_in_c), _ptr(w_out_c), _ptr(dy_c), _ptr(daw), _ptr(dent),
             _ptr(attn_w), _ptr(probs), _ptr(saved_o), _ptr(saved_v), _ptr(dx), _ptr(dquery), _ptr(dw_in), _ptr(db_in),
             _ptr(dw_out), _ptr(db_out), _ptr(ws), ws_bytes,
-            None if _lib.stage_events_bwd is None else ctypes.addressof(_lib.stage_events_bwd),
+            None if opts.stage_events is None else ctypes.addressof(opts.stage_events[1]),
             _DTYPES[out_dt], 0 if saved_o_lo is None else _lib.AECF_HILO_GRADS, _ptr(saved_prep),
-            None if early is None else early.cuda_event, _ptr(saved_o_lo))
+            None if early is None else early.cuda_event, _ptr(saved_o_lo), float(gscale))
         _lib.check(lib.aecf_pool_backward(ctypes.byref(desc), ctypes.byref(args), _stream()), "aecf_pool_backward")
         flat32 = None
         if keep32:
-            # autograd gets this rank's sums rounded to the parameters' dtype (what it would have got anyway); the float32 run
-            # stays behind for the collective, which rounds the MEAN once into the same allocation
+            # the float32 run stays behind for the collective, which rounds the MEAN once into the allocation autograd holds.
+            # What autograd gets meanwhile: this rank's sums rounded to the parameters' dtype -- unless the collective is certain
+            # to overwrite them before anyone may look (GradOverlap's hook is about to mutate flat32 on its side stream, so a cast
+            # on this stream would race it; DpState.defer_rounding: the caller promised to call all_reduce_grads): then the
+            # tensors stay uninitialised and the backward has no cast launch at all
             flat32 = flat
-            flat = flat32.to(gdt)
+            flat = torch.empty_like(flat32, dtype=gdt) if (hook is not None or dp_.defer_rounding) else flat32.to(gdt)
             dquery, dw_in, db_in, dw_out, db_out = flat.split([E, 3 * E * E, 3 * E, E * E, E])
             dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
-            if len(_f32_sums) > 8:
-                _f32_sums.clear()
-            _f32_sums[flat.untyped_storage().data_ptr()] = (flat, flat32, flat._version)
+        if dp_ is not None:
+            dp_.last = (flat, flat32, flat._version, gscale != 1.0)     # one entry per module, replaced by every backward
         if hook is not None:
-            hook(flat, early, flat32)              # [dquery | dw_in | db_in | dw_out | db_out]: final once `early` has fired
+            hook(flat, early, flat32, dp_)         # [dquery | dw_in | db_in | dw_out | db_out]: final once `early` has fired
         needs = ctx.needs_input_grad
         return (dx if needs[0] else None,
                 dquery.to(qd).reshape(ctx.q_shape) if needs[1] else None,
@@ -327,7 +391,7 @@ class _PoolFunction(torch.autograd.Function):
                 db_in.to(bid) if (ctx.has_bias[0] and needs[3]) else None,
                 dw_out.to(wod) if needs[4] else None,
                 db_out.to(bod) if (ctx.has_bias[1] and needs[5]) else None,
-                None, None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def precise_forward_backward(x: torch.Tensor, query: torch.Tensor, w_in: torch.Tensor, b_in: Optional[torch.Tensor],
@@ -689,9 +753,14 @@ class MultimodalAttentionPool(nn.Module):
     order and state_dict keys as the reference); its ``forward`` is never called -- the arithmetic runs
     in ``libaecf_hip.so``.
 
-    Built natively: one query shared by the batch (``fusion_query.expand(B, -1, -1)``, tgt_len 1),
-    ``value is key``, optional ``key_padding_mask``, dropout 0, bf16 or fp32.  Other argument
-    combinations raise NotImplementedError (they are not silently routed to PyTorch).
+    Hot path (the fused kernels): one query shared by the batch (``fusion_query.expand(B, -1, -1)``, tgt_len 1),
+    ``value is key``, optional boolean ``key_padding_mask``, dropout 0, bf16 or fp32.  Every other argument combination
+    ``nn.MultiheadAttention`` takes here (per-sample queries, tgt_len > 1, key != value, attn_mask, float masks, attention
+    dropout, embedding sizes the fused kernels do not tile) runs on the general kernels (``_forward_general``); only dtypes
+    other than bfloat16 / float32 raise NotImplementedError.  Nothing is routed to PyTorch.
+
+    ``self.options`` (``PoolOptions``): per-module switches of the fused path; ``aecf_amd.dp.attach(pool)`` makes the module
+    data-parallel (gradients pre-scaled by 1 / world, float32 sums kept for the collective).
     """
 
     def __init__(self, embed_dim: int, num_heads: int = 1, dropout: float = 0.0, bias: bool = True,
@@ -713,6 +782,13 @@ class MultimodalAttentionPool(nn.Module):
         self.attention = nn.MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads, dropout=dropout,    # ref :399-407
                                                bias=bias, batch_first=batch_first, device=device, dtype=dtype)
         self._cast_cache: Dict[str, Any] = {}
+        self.options = PoolOptions()
+
+    def _options(self) -> PoolOptions:
+        o = self.__dict__.get("options")
+        if o is None:                              # (a module unpickled from a build that had no per-module options)
+            o = self.options = PoolOptions()
+        return o
 
     def invalidate_cast_cache(self) -> None:
         """Forget the activation-dtype copies of the parameters (see _activation_dtype_params).  Call it after changing a
@@ -746,10 +822,20 @@ class MultimodalAttentionPool(nn.Module):
                 key_padding_mask: Optional[torch.Tensor] = None, attn_mask: Optional[torch.Tensor] = None,
                 return_info: bool = False, use_checkpoint: bool = False, *,
                 uniforms: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
+                batch_shard: Optional[Tuple[int, int]] = None,
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, Dict[str, Any]]]:
         # ``uniforms`` / ``generator`` (keyword-only, not in the reference): source of the curriculum mask's float32
-        # uniforms, [B, tgt_len, src_len] (see _draw_uniforms; data-parallel callers pass their shard of
-        # dp.global_uniforms).  Ignored when no training-mode curriculum masking runs.
+        # uniforms, [B, tgt_len, src_len] (see _draw_uniforms).  Ignored when no training-mode curriculum masking runs.
+        # ``batch_shard = (first_row, global_batch)`` (keyword-only, data parallel): this call's rows are rows
+        # [first_row, first_row + B) of a global batch whose mask uniforms are ONE draw of [global_batch, tgt_len, src_len]
+        # from ``generator`` (default: the device's default generator) -- every rank seeds that generator alike and names its
+        # shard; the statistics kernel evaluates the rank's elements of the global draw (no tensor, no launch) and the
+        # generator advances as the global call would, so N-rank masks are the one-rank masks bit for bit.
+        if batch_shard is not None:
+            row0, global_batch = int(batch_shard[0]), int(batch_shard[1])
+            nrows = query.shape[0] if self.batch_first else query.shape[1]
+            if row0 < 0 or row0 + nrows > global_batch:
+                raise ValueError(f"batch_shard {batch_shard} does not hold this call's {nrows} rows")
         # type / shape validation: ref :450-498 (messages identical)
         if not isinstance(query, torch.Tensor):
             raise TypeError(f"Expected query to be torch.Tensor, got {type(query)}")
@@ -830,6 +916,9 @@ class MultimodalAttentionPool(nn.Module):
         if (q_base is None or not same_kv or attn_mask is not None or dropping or float_kpm
                 or (not fast_ok and general_ok) or pad_to is not None):
             # everything outside the shared-query hot path: the general attention kernels
+            if (batch_shard is not None and uniforms is None and self.curriculum_masking is not None
+                    and self.curriculum_masking.training and src_len > 1):
+                uniforms = _draw_uniforms((global_batch, tgt_len, src_len), key.device, None, generator)[row0:row0 + batch_size]
             return self._forward_general(q_bf, x, value if self.batch_first else value.transpose(0, 1),
                                          key_padding_mask, attn_mask, return_info, batch_size, tgt_len, src_len,
                                          uniforms, generator, pad_to)
@@ -840,6 +929,7 @@ class MultimodalAttentionPool(nn.Module):
             kpm = key_padding_mask.to(device=x.device, dtype=torch.uint8).contiguous()
 
         cm = self.curriculum_masking
+        opts = self._options()
         mask_mode = 0
         mask_u = philox = None
         if cm is not None:
@@ -849,10 +939,13 @@ class MultimodalAttentionPool(nn.Module):
             if mask_mode == 1:
                 # one float32 uniform per weight element, row-major, default generator (ref :204): drawn by the statistics
                 # kernel itself from the generator's (seed, offset) where that can be read on the host, else as a tensor
-                if uniforms is None and _DRAW_IN_KERNEL:
-                    philox = _philox_draw(batch_size * tgt_len * src_len, x.device, generator)
+                draw_rows, row0 = (batch_size, 0) if (batch_shard is None or uniforms is not None) else (global_batch, row0)
+                if uniforms is None and opts.draw_in_kernel:
+                    philox = _philox_draw(draw_rows * tgt_len * src_len, x.device, generator, row0 * tgt_len * src_len)
                 if philox is None:
-                    mask_u = _draw_uniforms((batch_size, tgt_len, src_len), x.device, uniforms, generator)
+                    mask_u = _draw_uniforms((draw_rows, tgt_len, src_len), x.device, uniforms, generator)
+                    if draw_rows != batch_size:
+                        mask_u = mask_u[row0:row0 + batch_size].contiguous()
         a = self.attention
         tgt_value = math.log(float(src_len)) * cm.entropy_target if mask_mode == 1 else None        # ref :273
         side: Dict[str, Any] = {}
@@ -861,7 +954,7 @@ class MultimodalAttentionPool(nn.Module):
             self.num_heads, mask_mode, 1 if cm is None else int(cm.min_active),
             0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8,
             False, tgt_value, self._activation_dtype_params(x.dtype) if a.in_proj_weight.dtype != x.dtype else None, side,
-            philox)
+            philox, opts)
 
         dt = x.dtype
         attn_output = y.unsqueeze(1) if self.batch_first else y.unsqueeze(0)          # [B,1,E] / [1,B,E]

@@ -1,7 +1,9 @@
 """AdamW of the example trainer as one launch (``aecf_adamw_step``; ref xrays/train_xrays_example.py:322-323, 376 uses
 ``torch.optim.AdamW(lr=1e-4, weight_decay=0.01)``).  Same update rule and the same state layout as torch's (per parameter:
 ``step`` -- a float32 scalar on the device --, ``exp_avg``, ``exp_avg_sq``), so state dicts move between the two; the step
-counters advance on the device, which makes ``step()`` capturable into a HIP graph without further flags."""
+counters advance on the device, which makes ``step()`` capturable into a HIP graph without further flags.  One limit under
+capture: the hyper-parameters (``lr`` included) are kernel ARGUMENTS, so a captured step replays with the values it was captured
+with -- a learning-rate schedule needs a re-capture (or the eager step) when the rate changes."""
 from __future__ import annotations
 
 import ctypes
@@ -20,12 +22,17 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tickets = {}
 
-    def _ticket(self, device, n):
+    def _ticket(self, device, group_index, n):
+        """Ticket words of one parameter group's launch, kept for the optimizer's lifetime: a buffer that has been handed to a
+        launch is NEVER freed or replaced (a captured graph replays with its address), a group that grows gets a new, larger one
+        next to it."""
         need = 65 * ((n + 23) // 24)                              # AECF_ADAMW_TICKET_WORDS per launch group
-        t = self._tickets.get(device)
-        if t is None or t.numel() < need:
-            t = torch.zeros(need, dtype=torch.int32, device=device)
-            self._tickets[device] = t
+        held = self._tickets.setdefault((device, group_index), [])
+        for t in held:
+            if t.numel() >= need:
+                return t
+        t = torch.zeros(max(need, 65 * 8), dtype=torch.int32, device=device)
+        held.append(t)
         return t
 
     @torch.no_grad()
@@ -36,8 +43,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         vp = ctypes.c_void_p
-        for group in self.param_groups:
-            ps = [p for p in group["params"] if p.grad is not None]
+        for gi, group in enumerate(self.param_groups):
+            if group.get("amsgrad") or group.get("maximize"):
+                # (a state dict loaded from torch.optim.AdamW can carry these; the kernel implements neither)
+                raise RuntimeError("FusedAdamW: amsgrad / maximize are not implemented by aecf_adamw_step")
+            ps = [p for p in group["params"] if p.grad is not None and p.numel() > 0]    # (torch skips empty tensors too)
             if not ps:
                 continue
             dev = ps[0].device
@@ -67,7 +77,7 @@ class FusedAdamW(torch.optim.Optimizer):
             _lib.check(lib.aecf_adamw_step(
                 len(ps), arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
                 arr([self.state[p]["exp_avg_sq"] for p in ps]), arr([self.state[p]["step"] for p in ps]),
-                (ctypes.c_int64 * len(ps))(*[p.numel() for p in ps]), self._ticket(dev, len(ps)).data_ptr(),
+                (ctypes.c_int64 * len(ps))(*[p.numel() for p in ps]), self._ticket(dev, gi, len(ps)).data_ptr(),
                 float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), _stream()),
                 "aecf_adamw_step")
         return loss

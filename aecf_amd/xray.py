@@ -391,9 +391,11 @@ class GraphedTrainStep:
             tunable.tuning_enable(True)
             if hasattr(tunable, "write_file_on_exit"):
                 tunable.write_file_on_exit(False)
-            else:                                             # (this torch writes its picks at exit: not into the caller's directory)
+            else:                                             # (this torch writes its picks at exit: into a file of this process's own)
                 import tempfile
-                tunable.set_filename(os.path.join(tempfile.gettempdir(), "aecf_tunableop.csv"))
+                fd, name = tempfile.mkstemp(prefix="aecf_tunableop_", suffix=".csv")
+                os.close(fd)
+                tunable.set_filename(name)
         self.model, self.optimizer, self.criterion = model, optimizer, criterion
         self.image = torch.zeros(batch, image_dim, device=device, dtype=dtype)
         self.text = torch.zeros(batch, text_dim, device=device, dtype=dtype)
@@ -425,7 +427,10 @@ class GraphedTrainStep:
                 for idx, st in live.items():
                     for name, val in st.items():
                         if torch.is_tensor(val):
-                            val.copy_(saved[idx][name])
+                            if idx in saved and name in saved[idx]:
+                                val.copy_(saved[idx][name])
+                            else:                            # state the warm-up steps created (the caller had none for it)
+                                val.zero_()
             else:                                            # fresh optimizer: moments and step counters back to zero
                 for st in optimizer.state.values():
                     for val in st.values():

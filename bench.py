@@ -50,7 +50,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16
-PROFILE_TAG = "r04"              # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
+PROFILE_TAG = "r05"              # profiles/<tag>_<config>_traffic.json: the rocprofv3 --pmc passes of this round
 STAGE_PASS_STEPS = 30            # steps of the per-stage HIP-event pass (roofline), run AFTER the timed region (warm)
 SETTLE_STEPS = 30                # untimed steps of a fresh process before the W warm-up steps (stated in the line) ...
 SETTLE_SECONDS = 2.0             # ... continued until the process has been on the GPU this long: the host's launch path gets ~25 %
@@ -73,7 +73,9 @@ NCE_KEYS = 65536                 # --contrastive: gathered keys of configs[2] (8
 NCE_TEMPERATURE = 0.07
 
 
-def make_inputs(cfg, device, seed_offset=0):
+def make_inputs(cfg, device, seed_offset=0, f32_params=False):
+    """f32_params: float32 MASTER parameters under bf16 activations (the usual mixed-precision training setup): the parameter
+    gradients are then float32-stored and the backward's weight-gradient products run on bf16 hi + lo operand pairs."""
     B, M, E, H, dtype, p = cfg
     import aecf_amd
     torch.manual_seed(2)
@@ -82,8 +84,9 @@ def make_inputs(cfg, device, seed_offset=0):
         pool.attention.in_proj_bias.normal_(0.0, 0.02)
         pool.attention.out_proj.bias.normal_(0.0, 0.02)
         query.copy_(torch.randn(1, 1, E, generator=torch.Generator().manual_seed(1)) * (2.0 / E) ** 0.5)
-    pool = pool.to(device=device, dtype=dtype)
-    query = torch.nn.Parameter(query.detach().to(device=device, dtype=dtype))
+    pdt = torch.float32 if f32_params else dtype
+    pool = pool.to(device=device, dtype=pdt)
+    query = torch.nn.Parameter(query.detach().to(device=device, dtype=pdt))
     g = torch.Generator(device=device).manual_seed(seed_offset)      # every rank its own samples
     x = torch.randn(B, M, E, device=device, generator=g).to(dtype).requires_grad_(True)
     dy = torch.randn(B, 1, E, device=device, generator=g).to(dtype)
@@ -91,12 +94,13 @@ def make_inputs(cfg, device, seed_offset=0):
     return pool, query, x, dy
 
 
-def step(pool, query, x, dy, params, dp_on, uniforms=None, overlap=None):
+def step(pool, query, x, dy, params, dp_on, shard=None, overlap=None):
     """One pass of the hot path over one resident batch: forward (+ entropy_loss) + backward (+ the gradient all-reduce
-    when data-parallel: ONE collective, issued behind the backward's last kernel (dx) on a side stream, dp.GradOverlap;
-    default: the same collective after the backward)."""
+    when data-parallel: ONE sum collective after the backward -- the backward has already folded 1 / world into the gradients
+    it stores, dp.attach -- or, `--overlap`, issued behind the backward's last kernel (dx) on a side stream, dp.GradOverlap).
+    `shard` = (first row, global batch): the rank's rows of ONE global mask draw, evaluated inside the statistics kernel."""
     B = x.shape[0]
-    out, info = pool(query.expand(B, -1, -1), x, return_info=True, uniforms=uniforms)
+    out, info = pool(query.expand(B, -1, -1), x, return_info=True, batch_shard=shard)
     ent_loss = pool.curriculum_masking.entropy_loss(info["entropy"])
     x.grad = None
     for p in params:
@@ -108,9 +112,9 @@ def step(pool, query, x, dy, params, dp_on, uniforms=None, overlap=None):
     else:
         torch.autograd.backward([out], [dy])
         if dp_on:
-            # ONE RCCL all-reduce (AVG) of the 4E^2+5E values, in place over the allocation the backward wrote them into
+            # ONE RCCL all-reduce (sum of pre-scaled values) of the 4E^2+5E gradients, over the run the backward wrote them into
             from aecf_amd.dp import all_reduce_grads
-            all_reduce_grads(params)
+            all_reduce_grads(params, rehearse=True)
     return out, ent_loss
 
 
@@ -138,13 +142,11 @@ class StageTimer:
                      [("bwd." + lib.aecf_pool_stage_name(1, i).decode()) for i in range(self.nb)]
         self.samples = [[] for _ in range(self.nf + self.nb)]
 
-    def arm(self):
-        self._lib.stage_events_fwd = self.fwd
-        self._lib.stage_events_bwd = self.bwd
+    def arm(self, pool):
+        pool.options.stage_events = (self.fwd, self.bwd)
 
-    def disarm(self):
-        self._lib.stage_events_fwd = None
-        self._lib.stage_events_bwd = None
+    def disarm(self, pool):
+        pool.options.stage_events = None
 
     def collect(self):
         ms = ctypes.c_float()
@@ -203,67 +205,77 @@ def physical_cores():
     return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(cfg, seconds_budget=20.0):
-    """The CPU oracle (oracle/aecf_oracle.py, a port of the reference's arithmetic) timed on this box's host
-    cores on a bounded sample of the same workload: forward (+ train-mode masking + entropy loss) + explicit backward,
-    float32 and bfloat16.  torch's intra-op pool is set to the thread count that measures fastest among {physical cores,
-    32, 16, 8} (a 8192-row sample does not feed 64+ threads: the reference itself ran 24 k samples/s on 8 threads,
-    BASELINE.md section 2); `cores` = physical cores available, `threads` = the pool size used."""
+def cpu_baseline(cfg, seconds_budget=30.0):
+    """The CPU oracle (oracle/aecf_oracle.py, a port of the reference's arithmetic) timed on this box's host cores ON THE
+    BENCHMARK'S OWN CONFIGURATION (SURVEY 8d / BASELINE.md section 3: same B, M, d; threads = physical cores): forward (+ train-mode
+    masking + entropy loss) + explicit backward in float32, one warm-up + best of 3.  torch's intra-op pool: a quick sweep over
+    {physical cores, 32, 16, 8} on an 8192-row sample picks a second candidate; the full batch is timed at the physical core
+    count AND at the sweep's best when they differ, both reported, `value` = the faster.  The 8192-row numbers (float32 sweep
+    and the bf16 leg -- torch's CPU bf16 kernels on the same arithmetic, ~5x slower than float32) stay in the line as `sample_8192`."""
     from oracle import aecf_oracle as O
     B, M, E, H, dtype, p = cfg
-    n = min(B, 8192)
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(n, M, E, generator=g)
+    x = torch.randn(B, M, E, generator=g)
     q = torch.randn(1, 1, E, generator=g) * (2.0 / E) ** 0.5
     w_in = torch.randn(3 * E, E, generator=g) / E ** 0.5
     b_in = torch.randn(3 * E, generator=g) * 0.02
     w_out = torch.randn(E, E, generator=g) / E ** 0.5
     b_out = torch.randn(E, generator=g) * 0.02
-    dy = torch.randn(n, 1, E, generator=g)
-    U = torch.rand(n, 1, M, generator=g)
+    dy = torch.randn(B, 1, E, generator=g)
+    U = torch.rand(B, 1, M, generator=g)
 
-    def make(dt):
-        xs, qs, wi, bi, wo, bo, dys = (t_.to(dt) for t_ in (x, q, w_in, b_in, w_out, b_out, dy))
+    def make(dt, n):
+        xs, qs, wi, bi, wo, bo, dys = (t_.to(dt) for t_ in (x[:n], q, w_in, b_in, w_out, b_out, dy[:n]))
+        Un = U[:n]
 
         def one():
             qe = qs.expand(n, -1, -1)
             f = O.mha_forward(qe, xs, xs, wi, bi, wo, bo, H)
-            m = O.curriculum_mask_train(f["wbar"].float(), U, p)
+            m = O.curriculum_mask_train(f["wbar"].float(), Un, p)
             O.entropy_loss(m["entropy"], M)
             O.mha_backward(qe, xs, xs, wi, bi, wo, H, f, dys, None)
         return one
 
-    def best_of(fn, budget, max_reps):
-        fn()
-        best, reps, t_all = 1e30, 0, time.perf_counter()
-        while reps < 3 or (time.perf_counter() - t_all < budget and reps < max_reps):
+    def best_of(fn, reps):
+        fn()                                               # warm-up
+        best = 1e30
+        for _ in range(reps):
             t0 = time.perf_counter()
             fn()
             best = min(best, time.perf_counter() - t0)
-            reps += 1
-        return best, reps
+        return best
 
+    t_start = time.perf_counter()
     cores = physical_cores()
     saved = torch.get_num_threads()
-    one32 = make(torch.float32)
+    ns = min(B, 8192)
+    small32 = make(torch.float32, ns)
     trial = {}
     for nt in sorted({cores, 32, 16, 8}):
         if nt <= cores:
             torch.set_num_threads(nt)
-            trial[nt] = best_of(one32, 0.5, 3)[0]
-    threads = min(trial, key=trial.get)
-    torch.set_num_threads(threads)
-    best, reps = best_of(one32, seconds_budget * 0.5, 20)
-    # "cores" = the threads actually used (the contract's meaning); the machine's physical / logical counts beside it
-    out = dict(value=n / best, unit="samples/s", cores=threads, threads=threads, physical_cores=cores, logical_cpus=os.cpu_count(), kind="port",
-               sample=f"{n} samples of the same [B,M={M},d={E}] workload, fp32, fwd (+ masking, entropy loss) + bwd, best of {reps}; "
-                      f"thread sweep {({k: round(n / v) for k, v in trial.items()})} samples/s")
-    try:      # bf16 leg (what torch's CPU bf16 kernels make of the same arithmetic), same step
-        best_b, _ = best_of(make(torch.bfloat16), seconds_budget * 0.3, 5)
-        out["value_bf16"] = n / best_b
-    except Exception as e:                      # a CPU without usable bf16 kernels: the fp32 leg stands alone
-        out["value_bf16"] = None
-        out["bf16_note"] = str(e)[:80]
+            trial[nt] = best_of(small32, 3)
+    sweep_best = min(trial, key=trial.get)
+    full32 = make(torch.float32, B) if B > ns else small32
+    full = {}
+    for nt in ([cores] if sweep_best == cores else [cores, sweep_best]):
+        torch.set_num_threads(nt)
+        full[nt] = best_of(full32, 3) if B > ns else trial[nt]
+        if time.perf_counter() - t_start > seconds_budget:
+            break
+    threads = min(full, key=full.get)
+    out = dict(value=B / full[threads], unit="samples/s", cores=threads, threads=threads, physical_cores=cores,
+               logical_cpus=os.cpu_count(), kind="port",
+               sample=f"the full [B={B}, M={M}, d={E}] batch of this config, fp32, fwd (+ masking, entropy loss) + bwd, one warm-up + "
+                      f"best of 3; samples/s by thread count {({k: round(B / v) for k, v in full.items()})}",
+               sample_8192={"rows": ns, "threads_sweep_samples_per_s": {k: round(ns / v) for k, v in trial.items()}})
+    if time.perf_counter() - t_start < seconds_budget:
+        try:      # bf16 leg (what torch's CPU bf16 kernels make of the same arithmetic), 8192-row sample
+            torch.set_num_threads(sweep_best)
+            out["sample_8192"]["value_bf16"] = ns / best_of(make(torch.bfloat16, ns), 2)
+        except Exception as e:                      # a CPU without usable bf16 kernels: the fp32 leg stands alone
+            out["sample_8192"]["bf16_note"] = str(e)[:80]
+    out["seconds"] = round(time.perf_counter() - t_start, 1)
     torch.set_num_threads(saved)
     return out
 
@@ -392,10 +404,23 @@ def bench_c4(args):
                      "device->host read of the routing counts; host_enqueue_ms ~ ms_per_step means the GPU waits for the host"),
             "cpu_baseline": None,
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_REAL_STDOUT = None
+
+
+def emit(line):
+    """The ONE JSON line, on the descriptor that was stdout when the process started (see main)."""
+    text = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(text.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, text)
 
 
 def main():
@@ -426,14 +451,25 @@ def main():
                          "EXPERIMENTAL -- never run over RCCL on real multi-GPU hardware by this build; default: one all-reduce "
                          "after the backward)")
     ap.add_argument("--no-overlap", action="store_true", help="(default behaviour; kept for older command lines)")
+    ap.add_argument("--f32-params", action="store_true",
+                    help="float32 master parameters under bf16 activations: float32-stored parameter gradients, the weight-gradient "
+                         "products on hi + lo operand pairs (north_star's 1e-3 on the gradients as they are stored)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="one rank: run the N > 1 step (attach, sharded in-kernel mask draw, the collective) on a ONE-rank RCCL "
+                         "group -- rehearses the RCCL call (and, with --graph, its capture) on a one-GPU box")
+    ap.add_argument("--no-strong-graph", action="store_true",
+                    help="N>1 weak scaling: do not attempt the graph-captured form of the strong-scaling point")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=30.0, help="budget of the CPU-oracle leg")
     args = ap.parse_args()
     globals()["SETTLE_SECONDS"] = args.settle_seconds
-    if args.hilo:
-        from aecf_amd import layer as _layer
-        _layer._HILO_GRADS = True
-
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner on stdout when its first communicator comes
+    # up (seen on this image), other libraries may too -- from here on file descriptor 1 is the process's stderr, and the line
+    # is written to the descriptor stdout had
+    sys.stdout.flush()
+    globals()["_REAL_STDOUT"] = os.dup(1)
+    os.dup2(2, 1)
     if args.config == "c4":
         return bench_c4(args)
 
@@ -443,10 +479,18 @@ def main():
     ndev = torch.cuda.device_count()
     dev_index = local % max(ndev, 1)          # rehearsal on a 1-GPU box: several ranks may share device 0
     backend = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         # RCCL ("nccl") over xGMI is the real path; AECF_DIST_BACKEND=gloo only rehearses the N>1 code on one GPU
         backend = os.environ.get("AECF_DIST_BACKEND", "nccl")
+        if world == 1:                               # --force-dp: a one-rank group of our own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -462,19 +506,24 @@ def main():
     else:
         lo, B, B_global = rank * Bc, Bc, world * Bc
     cfg = (B, M, E, H, dtype, p)
-    pool, query, x, dy = make_inputs(cfg, device, seed_offset=rank)
+    pool, query, x, dy = make_inputs(cfg, device, seed_offset=rank, f32_params=args.f32_params)
+    if args.hilo:
+        pool.options.hilo_grads = True
     params = [query] + list(pool.parameters())
-    if world > 1:
-        dp.broadcast_parameters(params)      # replicas start identical whatever the ranks' construction RNG did
-        # (no dp.probe_avg_support here: the step uses divide + ReduceOp.SUM, which every backend takes; ReduceOp.AVG would
-        #  save one 1 M-element divide per step and its start-up probe is one more thing that has never run on real RCCL)
-    # curriculum-mask uniforms (public `uniforms=` argument).  Weak scaling: the global draw is DEFINED slot by slot -- rows
-    # [r Bc, (r + 1) Bc) come from the generator seeded 1234 + r -- so a rank draws exactly its own Bc rows per step (per-rank work
-    # does not grow with N) and any number of ranks, or one rank walking the slots, sees the same global tensor.  Strong scaling
-    # (shard sizes change with N): every rank draws the same global tensor from the shared seed and uses its rows.
-    ugen = None
-    if world > 1:
-        ugen = torch.Generator(device=device).manual_seed(1234 + (rank if args.scaling != "strong" else 0))
+    dp_on = world > 1 or args.force_dp
+    shard = None
+    if dp_on:
+        if world > 1:
+            dp.broadcast_parameters(params)  # replicas start identical whatever the ranks' construction RNG did
+        # The N > 1 step is the one-rank step plus ONE collective: the backward folds 1 / world into the gradients as it stores
+        # them and (bf16 parameters) leaves its float32 sums for the collective, which rounds the mean once into the allocation
+        # autograd holds -- no divide launch, no cast in the backward (defer_rounding: this loop always reduces before it reads).
+        dp.attach(pool, defer_rounding=True, world=max(world, 2) if args.force_dp else None)
+        # curriculum mask: every rank seeds its device generator alike and names its rows of the global batch; the statistics
+        # kernel evaluates the rank's elements of ONE global draw (ABI v9) -- no torch.rand launch, no uniforms tensor, and the
+        # masks are those of one rank running the global batch
+        torch.cuda.manual_seed(1234)
+        shard = (lo, B_global)
     overlap = dp.GradOverlap(params=params) if (world > 1 and args.overlap and not args.no_overlap) else None
 
     # --contrastive (configs[2]): the paired view.  zb_local = this rank's rows of the other view (resident, as the output of a
@@ -494,10 +543,10 @@ def main():
             nce = dict(offset=lo, keys=None, cols=B_global)
         nce["zb"] = zb_local
 
-    def contrastive_step(u):
+    def contrastive_step():
         """pool forward -> fused rows z; symmetric InfoNCE of z against every rank's rows of the paired view + entropy
         regulariser (one operator); backward through the loss and the pool (+ the gradient all-reduce when N > 1)."""
-        out, info = pool(query.expand(B, -1, -1), x, return_info=True, uniforms=u)
+        out, info = pool(query.expand(B, -1, -1), x, return_info=True, batch_shard=shard)
         nb = losses.l2_normalize(nce["zb"])
         if world == 1:
             nb_all = nce["keys"]
@@ -510,21 +559,15 @@ def main():
         for prm in params:
             prm.grad = None
         loss.backward()
-        if world > 1:
+        if dp_on:
             from aecf_amd.dp import all_reduce_grads
-            all_reduce_grads(params)
+            all_reduce_grads(params, rehearse=True)
         return out, loss
 
     def one_step():
-        u = None
-        if ugen is not None:
-            if args.scaling == "strong":
-                u = torch.rand(B_global, 1, M, device=device, dtype=torch.float32, generator=ugen)[lo:lo + B]
-            else:
-                u = torch.rand(B, 1, M, device=device, dtype=torch.float32, generator=ugen)
         if nce is not None:
-            return contrastive_step(u)
-        return step(pool, query, x, dy, params, world > 1, u, overlap)
+            return contrastive_step()
+        return step(pool, query, x, dy, params, dp_on, shard, overlap)
 
     def barrier():
         if world > 1:
@@ -534,8 +577,13 @@ def main():
 
     graph = None
     if args.graph:
-        if world > 1:
-            sys.exit("--graph captures a one-rank step")
+        if world > 1 and backend != "nccl":
+            sys.exit("--graph with N > 1 captures the RCCL collective with the step; the gloo rehearsal has no stream collectives")
+        if overlap is not None:
+            sys.exit("--graph and --overlap are alternatives")
+        # N > 1 (round 5): the collective is captured with the step (RCCL enqueues on the capturing stream) -- UNTESTED on real
+        # multi-GPU hardware by this build, exercised on one GPU with a one-rank RCCL group (--force-dp); inside a capture the
+        # mask uniforms are the tensor path (torch's graph-safe generator state; the kernel cannot read a host-side offset)
         eager_step = one_step
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream())
@@ -582,14 +630,37 @@ def main():
     stages = None
     st = StageTimer()                    # (every rank runs the pass -- the same tail for all -- rank 0 reports it)
     for _ in range(STAGE_PASS_STEPS):
-        st.arm()
+        st.arm(pool)
         step(pool, query, x, dy, params, False, None)
-        st.disarm()
+        st.disarm(pool)
         torch.cuda.synchronize()
         st.collect()
     # N > 1, weak scaling (what the driver's one run per N measures): the STRONG-scaling point of the same N rides along in the
     # same line (field "strong_scaling"), after the timed region and the stage pass -- the config's global batch sharded over the
     # ranks, same step, same collective -- so that one lease of a multi-GPU node yields both curves
+    # the collective on its own: HIP events on the launch stream around all_reduce_grads (which includes the one rounding of the
+    # float32 mean into bf16 parameters' gradients), over extra steps after the timed region; median over the steps, max over ranks
+    collective_ms = None
+    if dp_on and nce is None:
+        from aecf_amd.dp import all_reduce_grads
+        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(STAGE_PASS_STEPS)]
+        for e0, e1 in cev:
+            out, _ = pool(query.expand(B, -1, -1), x, return_info=True, batch_shard=shard)
+            x.grad = None
+            for p_ in params:
+                p_.grad = None
+            torch.autograd.backward([out], [dy])
+            e0.record()
+            all_reduce_grads(params, rehearse=True)
+            e1.record()
+        torch.cuda.synchronize()
+        cms = sorted(e0.elapsed_time(e1) for e0, e1 in cev)
+        collective_ms = cms[len(cms) // 2]
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([collective_ms], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            collective_ms = float(tt[0].item())
     strong = None
     if world > 1 and args.scaling == "weak" and nce is None and graph is None:
         import torch.distributed as dist
@@ -597,23 +668,51 @@ def main():
         bs = hi_s - lo_s
         xs = x.detach()[:bs].clone().requires_grad_(True)
         dys = dy[:bs]
-        sgen = torch.Generator(device=device).manual_seed(4321)
+        torch.cuda.manual_seed(4321)                      # (every rank alike: the strong point's global mask draw)
 
-        def strong_step():
-            us = torch.rand(Bc, 1, M, device=device, dtype=torch.float32, generator=sgen)[lo_s:hi_s]
-            return step(pool, query, xs, dys, params, True, us, overlap)
-        for _ in range(max(5, args.warmup)):
-            strong_step()
-        barrier()
-        ts0 = time.perf_counter()
-        for _ in range(args.steps):
-            strong_step()
-        barrier()
-        tt = torch.tensor([time.perf_counter() - ts0], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        sec_s = float(tt[0].item()) / args.steps
+        def strong_eager():
+            return step(pool, query, xs, dys, params, True, (lo_s, Bc), overlap)
+
+        def time_strong(fn):
+            for _ in range(max(5, args.warmup)):
+                fn()
+            barrier()
+            ts0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            barrier()
+            tt = torch.tensor([time.perf_counter() - ts0], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt[0].item()) / args.steps
+        sec_s = time_strong(strong_eager)
         strong = {"value": Bc / sec_s, "unit": "samples/s", "ms_per_step": sec_s * 1e3, "global_batch": Bc,
-                  "per_gpu_batch": bs, "scaling": "strong", "steps": args.steps}
+                  "per_gpu_batch": bs, "scaling": "strong", "steps": args.steps, "graph_replay": False}
+        # ... and the same point with the step (collective included) captured once and replayed: at B / N rows per GPU the eager
+        # step is bound by the host's ~0.2 ms of Python per step, which is not what strong scaling is asked about.  RCCL enqueues
+        # on the capturing stream; this has never run on real multi-GPU hardware by this build, so any failure to capture keeps
+        # the eager number (every rank still issues one collective per step either way)
+        if backend == "nccl" and overlap is None and not args.no_strong_graph:
+            captured, why = None, None
+            try:
+                side = torch.cuda.Stream(device=device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        strong_eager()
+                torch.cuda.current_stream().wait_stream(side)
+                captured = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(captured):
+                    strong_eager()
+            except Exception as e:                        # noqa: BLE001
+                captured, why = None, f"{type(e).__name__}: {str(e)[:120]}"
+            ok = torch.tensor([1 if captured is not None else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # replay only if EVERY rank captured
+            if int(ok.item()) == 1:
+                sec_g = time_strong(captured.replay)
+                strong["graph"] = {"value": Bc / sec_g, "ms_per_step": sec_g * 1e3, "graph_replay": True,
+                                   "note": "step + RCCL all-reduce captured as one HIP graph (untested on RCCL before this run)"}
+            else:
+                strong["graph"] = {"value": None, "graph_replay": False, "note": why or "another rank failed to capture"}
     nce_ms = None
     if nce is not None:                  # the two C-ABI calls of the loss side, HIP events on the launch stream
         from aecf_amd import _lib
@@ -692,7 +791,7 @@ def main():
             path_bytes += s_bytes * (2 * E + 2 * nce["cols"]) + 4 * E        # z, dz, the E row written + re-read twice ... per sample
         cb = None
         if not (args.no_cpu_baseline or world > 1):
-            cb = cpu_baseline(cfg)
+            cb = cpu_baseline(cfg, args.cpu_baseline_seconds)
             cb["cpu_model"] = cpu_model()
         workload = f"{args.config}: [B={B} per GPU, M={M}, d={E}, {H} heads] mask_prob={p} train-mode curriculum masking, fwd+bwd"
         coll = None if world == 1 else (
@@ -703,6 +802,27 @@ def main():
                          f"(T={NCE_TEMPERATURE}) + entropy loss, one logits block for both directions")
             if world > 1:
                 coll += f"; all-gather of [{B},{E}] rows + reduce-scatter of their gradient; all-reduce of {nce['cols']} column sums"
+        # every hipEventRecord of the stage pass is a marker the stream has to process (~5 us): a stage with no launch in it
+        # reads that much.  Reported as measured; `sum_ms` adds everything up, `launch_stages_sum_ms` leaves the empty stages
+        # out -- the figure to hold against ms_per_step (it still carries one marker per non-empty stage)
+        empty = [k for k, v in stages.items() if k.startswith(("fwd.", "bwd.")) and v < 0.008]
+        pool_stage_sum = sum(v for k, v in stages.items() if k.startswith(("fwd.", "bwd.")))
+        stage_pass = {"steps": STAGE_PASS_STEPS, "when": "after the timed region", "stat": "median",
+                      "sum_ms": pool_stage_sum, "empty_stages": empty,
+                      "event_overhead_ms_per_mark": (sum(stages[k] for k in empty) / len(empty)) if empty else None,
+                      "launch_stages_sum_ms": pool_stage_sum - sum(stages[k] for k in empty)}
+        pdt = next(iter(pool.parameters())).dtype
+        hilo_on = pool.options.hilo_grads if pool.options.hilo_grads is not None else (pdt != dtype)
+        grad_mode = ("float32-stored parameter gradients, weight-gradient products on bf16 hi + lo operand pairs (AECF_HILO_GRADS)"
+                     if (hilo_on and dtype == torch.bfloat16) else
+                     ("bf16-stored parameter gradients (bf16 parameters): float32 batch sums rounded once"
+                      if pdt == torch.bfloat16 else "float32"))
+        extra_launches = None
+        if dp_on:
+            extra_launches = {"mask_uniforms_draw": 0 if (graph is None and pool.options.draw_in_kernel) else 1,
+                              "gradient_divide": 0, "cast_in_backward": 0,
+                              "round_mean_into_bf16_grads": 1 if pdt == torch.bfloat16 else 0,
+                              "collectives": 1}
         line = {
             "metric": "fused samples/sec (fwd+bwd)", "value": B_global / sec, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settled,
@@ -716,15 +836,18 @@ def main():
             "path_hbm_frac": path_bytes * B / sec / 1e9 / HBM_PEAK_GBS,
             "path_mfma_frac": path_flops * B / sec / 1e12 / MFMA_PEAK_TFLOPS,
             "stage_ms": stages,
-            "stage_pass": {"steps": STAGE_PASS_STEPS, "when": "after the timed region", "stat": "median"},
+            "stage_pass": stage_pass,
+            "weight_grad_mode": grad_mode,
             "graph_replay": graph is not None,
             "cpu_baseline": cb,
+            "collective_ms": collective_ms,
+            "extra_launches_per_step": extra_launches,
             "strong_scaling": strong,
             "collective_library": None if world == 1 else (
                 f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())}" if backend == "nccl" else backend),
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        emit(line)
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         dist.barrier()                 # rank 0 is still measuring its stage times: leave together
         dist.destroy_process_group()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AECF_ABI_VERSION 8
+#define AECF_ABI_VERSION 9
 
 typedef enum aecf_status {
     AECF_OK = 0,
@@ -140,17 +140,27 @@ typedef struct aecf_pool_fwd_args {
     /* ABI v8, AECF_HILO_GRADS: [B,E] dtype, the LOW part of saved_o -- bf16(o - float(bf16(o))) -- written beside it by the
      * value projection; hand both to the backward (see aecf_pool_bwd_args.saved_o_lo).  Required with the flag. */
     void* saved_o_lo;
+    /* ABI v9, AECF_DRAW_UNIFORMS: this call's rows are rows [r0, r0 + B) of a LARGER batch whose mask uniforms are ONE draw
+     * `torch.rand(B_global * M)` -- a data-parallel rank's shard.  philox_element0 = r0 * M is the element of that draw the
+     * call's first weight element is, and philox_threads is the thread count of the GLOBAL launch; weight element i of the call
+     * takes the value the global tensor holds at philox_element0 + i.  Every rank passes the same (seed, offset) and advances its
+     * generator by what the global call consumes: N-rank masks are the one-rank masks bit for bit with no uniforms tensor and no
+     * launch.  0 = the call is the whole draw. */
+    int64_t philox_element0;
 } aecf_pool_fwd_args;
 
 #define AECF_PRECISE 1
 #define AECF_DRAW_UNIFORMS 2
 /* AECF_HILO_GRADS (bf16; aecf_pool_hilo_bwd_workspace_bytes(desc) > 0 says the shape is built): the WEIGHT-GRADIENT products
- * of the backward take both operands as bf16 hi + lo pairs -- dW_o = dy^T (o_hi + o_lo), dW_v = do_hi^T P_hi + do_hi^T P_lo +
- * do_lo^T P_hi with do = dy W_o and the pooled rows P split where they are formed -- so that float32-stored parameter gradients
- * are float32-accurate (the bf16 roundings of the two derived operands are what puts the default path's dW at 2-4e-3 of fp32
- * math).  Everything else (y, dx, the kernels) is the default path.  Set it on BOTH calls.  Cost: three more launches of the
- * batch-reduction kernels per step (profiles/r04_c2_hilo_time.txt); the backward workspace is the larger
- * aecf_pool_hilo_bwd_workspace_bytes. */
+ * of the backward take the operands that are derived values as bf16 hi + lo pairs -- dW_o = dy^T (o_hi + o_lo), dW_v = do_hi^T
+ * P_hi + do_hi^T P_lo + do_lo^T P_hi with do = dy W_o and the pooled rows P split where they are formed, the key-side reduction
+ * from do_hi + do_lo -- so that float32-STORED parameter gradients are float32-accurate (the bf16 roundings of the derived
+ * operands are what puts the default path's dW at 1.3 - 2.3e-3 of fp32 math at the headline shape: above north_star's 1e-3).
+ * Everything else (y, dx, the kernels) is the default path.  Set it on BOTH calls.  ONE launch per product (round 5,
+ * aecf_gemm_tn_hilo.hip: hi and lo tiles of a step side by side in LDS, one accumulator set, one slab set); the backward
+ * workspace is the larger aecf_pool_hilo_bwd_workspace_bytes (do_lo).  The Python layer sets it by itself whenever the parameter
+ * gradients are float32-stored (float32 master weights under bf16 activations); with bf16 parameters the gradient's own
+ * rounding (2^-9) hides what the flag buys. */
 #define AECF_HILO_GRADS 4
 
 /* Backward (autograd transpose of the above). */
@@ -188,6 +198,10 @@ typedef struct aecf_pool_bwd_args {
      * NULL = off. */
     void* param_grads_event;
     const void* saved_o_lo;      /* AECF_HILO_GRADS: the forward's low part of saved_o, else NULL (ABI v8) */
+    /* ABI v9: the five parameter gradients are multiplied by grad_scale as their float32 batch sums are stored (before the one
+     * rounding of a bf16 gradient) -- a data-parallel caller passes 1 / world, so that the gradient average is ONE sum
+     * all-reduce with no divide launch around it.  dx is not scaled.  0 = 1 (off). */
+    float grad_scale;
 } aecf_pool_bwd_args;
 
 #define AECF_FWD_STAGES 4   /* prep, gate, vproj, outproj */
@@ -215,9 +229,9 @@ size_t aecf_pool_hilo_bwd_workspace_bytes(const aecf_pool_desc* d);
 size_t aecf_pool_prep_bytes(const aecf_pool_desc* d);
 
 /* The generator call of AECF_DRAW_UNIFORMS on its own (tests, callers that want the tensor): out[i], i < n, = the float32
- * uniform described at aecf_pool_fwd_args.philox_seed.  aecf_philox_host evaluates one element on the host (known-answer
+ * uniform described at aecf_pool_fwd_args.philox_seed for element element0 + i of the draw (element0: see philox_element0).  aecf_philox_host evaluates one element on the host (known-answer
  * tests; `raw` != NULL additionally receives the four 32-bit outputs of the Philox4x32-10 block the element comes from). */
-int aecf_philox_uniforms(int64_t n, uint64_t seed, uint64_t offset, uint32_t threads, float* out, void* stream);
+int aecf_philox_uniforms(int64_t n, uint64_t seed, uint64_t offset, uint32_t threads, int64_t element0, float* out, void* stream);
 float aecf_philox_host(uint64_t seed, uint64_t offset, uint32_t threads, int64_t element, uint32_t* raw);
 
 int aecf_pool_forward(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, void* stream);

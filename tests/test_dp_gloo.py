@@ -259,3 +259,67 @@ def test_bf16_gradients_travel_as_float32_by_default():
         assert in_place and is_bf16
         got = torch.cat([torch.from_numpy(ga), torch.from_numpy(gb)])
         assert torch.equal(got, want), rank
+
+
+class _StandInPool(torch.nn.Module):
+    """What dp.attach needs of a pool module: parameters and ``_options()`` (aecf_amd/layer.py: PoolOptions)."""
+
+    def __init__(self):
+        super().__init__()
+        from aecf_amd.layer import PoolOptions
+        self.w = torch.nn.Parameter(torch.zeros(60, 64, dtype=torch.bfloat16))
+        self.b = torch.nn.Parameter(torch.zeros(256, dtype=torch.bfloat16))
+        self.options = PoolOptions()
+
+    def _options(self):
+        return self.options
+
+
+def _attached_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pool = _StandInPool()
+        st = dp.attach(pool, defer_rounding=True)
+        g = torch.Generator().manual_seed(100 + rank)
+        sums = torch.randn(4096, generator=g) * 3.0                  # this rank's float32 batch sums
+        wide = sums * st.grad_scale                                  # ... as the backward stores them (aecf_pool_bwd_args.grad_scale)
+        flat = torch.full((4096,), float("nan"), dtype=torch.bfloat16)     # deferred rounding: autograd's tensors are not written
+        pool.w.grad, pool.b.grad = flat[:3840].view(60, 64), flat[3840:]
+        st.last = (flat, wide, flat._version, True)
+        ptr = pool.w.grad.data_ptr()
+        dp.all_reduce_grads([pool.w, pool.b])
+        consumed = st.last is None
+        # a second call finds nothing left behind: the bf16 values themselves travel (as float32), divided by world
+        again = flat.float().clone()
+        dp.all_reduce_grads([pool.w, pool.b])
+        q.put((rank, st.grad_scale, sums.numpy(), again.numpy(), flat.float().numpy(), pool.w.grad.data_ptr() == ptr, consumed))
+        dp.detach(pool)
+        assert pool.options.dp is None and not dp._states_of([pool.w])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_attached_module_gradients_are_prescaled_and_rounded_once():
+    """dp.attach (round 5): the backward stores sums / world and keeps them in float32; all_reduce_grads then issues a SUM with
+    no divide, rounds the mean ONCE into the (until then unwritten) bf16 allocation, and consumes the record."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_attached_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    mean = (torch.from_numpy(res[0][2]) * 0.5 + torch.from_numpy(res[1][2]) * 0.5)
+    want = mean.to(torch.bfloat16).float()
+    for rank, scale, _, first, second, in_place, consumed in res:
+        assert scale == 0.5 and in_place and consumed
+        assert torch.equal(torch.from_numpy(first), want), rank
+        # the second, plain call averaged two identical tensors again: unchanged up to one more rounding of the same value
+        assert torch.equal(torch.from_numpy(second), want), rank

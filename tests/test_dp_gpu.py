@@ -48,9 +48,9 @@ def _build(dev, dtype, seed):
     return query, pool
 
 
-def _run_shard(query, pool, x, dy, u, dev, scale):
+def _run_shard(query, pool, x, dy, u, dev, scale, shard=None):
     xs = x.to(dev).requires_grad_(True)
-    out, info = pool(query.expand(xs.shape[0], -1, -1), xs, return_info=True, uniforms=u)
+    out, info = pool(query.expand(xs.shape[0], -1, -1), xs, return_info=True, uniforms=u, batch_shard=shard)
     ent = pool.curriculum_masking.entropy_loss(info["entropy"])
     loss = ((out.float() * dy.to(dev).float()).sum() / B + 1e-2 * info["attention_weights"].float().pow(2).sum() / B
             + 0.0 * ent) * scale
@@ -73,6 +73,8 @@ def _worker(rank, world, port, backend, dtype, q):
         params = [query] + list(pool.parameters())
         dp.broadcast_parameters(params)
         dp.probe_avg_support(params[0].dtype, dev)
+        st = dp.attach(pool)          # 1 / world folded into the backward's gradient stores; float32 sums kept for bf16 parameters
+        assert st.world == world and st.grad_scale == 1.0 / world
         lo, hi = dp.shard_bounds(B, rank, world)
         u = dp.shard_batch(dp.global_uniforms(B, 1, M, seed=77, device=dev), rank, world)
         # the loss is a SUM over the shard divided by the global B, so the average over ranks needs the factor `world`
@@ -80,6 +82,28 @@ def _worker(rank, world, port, backend, dtype, q):
         dp.all_reduce_grads(params)
         torch.cuda.synchronize()
         plain = [p.grad.clone() for p in params]
+        # the same step with NO uniforms tensor: every rank seeds its generator alike and names its rows of the global batch;
+        # the statistics kernel evaluates the rank's elements of the one global draw (ABI v9: philox_element0)
+        for p in params:
+            p.grad = None
+        torch.cuda.manual_seed(4242)
+        out_k, masked_k, dx_k = _run_shard(query, pool, x[lo:hi], dy[lo:hi], None, dev, float(world), shard=(lo, B))
+        dp.all_reduce_grads(params)
+        torch.cuda.synchronize()
+        drawn = (out_k.float().cpu().numpy(), masked_k.float().cpu().numpy(), dx_k.float().cpu().numpy(),
+                 [p.grad.float().cpu().numpy() for p in params])
+        if dtype == torch.bfloat16:
+            # defer_rounding: the bf16 tensors autograd holds stay uninitialised until the collective rounds the float32 mean
+            # into them -- no cast launch in the backward, the same bits afterwards
+            for p in params:
+                p.grad = None
+            st.defer_rounding = True
+            _run_shard(query, pool, x[lo:hi], dy[lo:hi], u, dev, float(world))
+            dp.all_reduce_grads(params)
+            torch.cuda.synchronize()
+            st.defer_rounding = False
+            for a_, p in zip(plain, params):
+                assert torch.equal(a_, p.grad), "deferred rounding differs from the cast-then-overwrite path" 
         # the same step with the out-projection gradients' all-reduce started behind the rest of the backward
         for p in params:
             p.grad = None
@@ -122,8 +146,7 @@ def _worker(rank, world, port, backend, dtype, q):
         # a backward that starts with gradients already set (accumulation): the hook is not installed, finish() reduces plainly
         overlap = dp.GradOverlap(params=params)
         with overlap:
-            from aecf_amd import layer as _layer
-            assert _layer._param_grads_hook is None
+            assert st.hook is None
         # bf16 transport (fp32=False) against the default float32 transport (`plain`)
         if dtype == torch.bfloat16:
             for p in params:
@@ -137,7 +160,7 @@ def _worker(rank, world, port, backend, dtype, q):
         for p, g in zip(params, plain):
             p.grad = g
         q.put((rank, lo, hi, out.float().cpu().numpy(), masked.float().cpu().numpy(), dx.float().cpu().numpy(),
-               [p.grad.float().cpu().numpy() for p in params], [p.detach().float().cpu().numpy() for p in params]))
+               [p.grad.float().cpu().numpy() for p in params], [p.detach().float().cpu().numpy() for p in params], drawn))
     finally:
         dist.destroy_process_group()
 
@@ -175,9 +198,24 @@ def test_two_ranks_equal_one_rank(dtype):
     # of all_reduce_grads for reduced-precision gradients) and rounds the mean once: at most three bf16 roundings against the
     # one-rank gradient (which carries one itself) -- 5e-3 of the largest element, not the 2e-2 a bf16 ring sum needed
     tol = 2e-5 if dtype == torch.float32 else 5e-3
-    for rank, lo, hi, o_r, m_r, dx_r, grads, _ in res:
+    for rank, lo, hi, o_r, m_r, dx_r, grads, _, _ in res:
         assert torch.equal(torch.from_numpy(o_r), out[lo:hi].float().cpu())           # per-sample outputs bit-equal
         assert torch.equal(torch.from_numpy(m_r), masked[lo:hi].float().cpu())        # masks independent of N
+        assert torch.equal(torch.from_numpy(dx_r), dx[lo:hi].float().cpu())
+        for g, p in zip(grads, params):
+            ref = p.grad.float().cpu()
+            err = (torch.from_numpy(g) - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert err < tol, (rank, tuple(ref.shape), err)
+    # the in-kernel draw: one rank drawing the whole batch from the same seed sees, row for row, what the two ranks drew
+    for p in params:
+        p.grad = None
+    torch.cuda.manual_seed(4242)
+    out, masked, dx = _run_shard(query, pool, x, dy, None, dev, 1.0)
+    torch.cuda.synchronize()
+    assert 0.02 < float((masked == 0).float().mean()) < 0.9                           # (it did mask something)
+    for rank, lo, hi, _, _, _, _, _, (o_r, m_r, dx_r, grads) in res:
+        assert torch.equal(torch.from_numpy(o_r), out[lo:hi].float().cpu())
+        assert torch.equal(torch.from_numpy(m_r), masked[lo:hi].float().cpu()), "N-rank masks differ from the one-rank masks"
         assert torch.equal(torch.from_numpy(dx_r), dx[lo:hi].float().cpu())
         for g, p in zip(grads, params):
             ref = p.grad.float().cpu()
@@ -219,6 +257,27 @@ def test_bench_weak_scaling_line_carries_the_strong_point():
     st = line["strong_scaling"]
     assert st["scaling"] == "strong" and st["global_batch"] == 4096 and st["per_gpu_batch"] == 2048 and st["value"] > 0
     assert line["collective_library"]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("graph", [False, True])
+def test_bench_force_dp_runs_the_rccl_step_on_one_gpu(graph):
+    """`bench.py --force-dp`: the N > 1 step (dp.attach: pre-scaled gradients, float32 sums, the sharded in-kernel mask draw,
+    ONE collective) on a one-rank RCCL group -- the RCCL call itself and, with --graph, its capture with the step into one HIP
+    graph, which is what the strong-scaling point replays on a multi-GPU node."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "AECF_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "5", "--warmup", "2", "--force-dp",
+           "--no-cpu-baseline", "--settle-seconds", "0"] + (["--graph"] if graph else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["graph_replay"] == graph and line["value"] > 0
+    assert line["collective_ms"] is not None and line["collective_ms"] > 0
+    ex = line["extra_launches_per_step"]
+    assert ex["gradient_divide"] == 0 and ex["cast_in_backward"] == 0 and ex["collectives"] == 1
+    assert ex["mask_uniforms_draw"] == (1 if graph else 0)
 
 
 @pytest.mark.timeout(600)

@@ -37,9 +37,11 @@ def test_header_symbols_are_exported(built_library):
 def test_struct_layout_matches_header():
     # include/aecf_hip.h: aecf_pool_desc = int64 + 6*int32 + 3*float = 44 -> padded to 48
     assert ctypes.sizeof(_lib.PoolDesc) == 48
-    assert ctypes.sizeof(_lib.PoolFwdArgs) == 32 * 8          # ABI v8: + philox_seed, philox_offset, philox_threads (+ pad), ent_loss, saved_o_lo
+    assert ctypes.sizeof(_lib.PoolFwdArgs) == 33 * 8          # ABI v9: + philox_element0
     assert _lib.PoolFwdArgs.philox_seed.offset == 216 and _lib.PoolFwdArgs.ent_loss.offset == 240
-    assert ctypes.sizeof(_lib.PoolBwdArgs) == 25 * 8          # ABI v8: + saved_o_lo
+    assert _lib.PoolFwdArgs.philox_element0.offset == 256
+    assert ctypes.sizeof(_lib.PoolBwdArgs) == 26 * 8          # ABI v9: + grad_scale (+ pad)
+    assert _lib.PoolBwdArgs.grad_scale.offset == 200
 
 
 def test_pool_check_and_workspace_sizes(built_library):

@@ -57,11 +57,12 @@ def _build_pool(g, dtype, curriculum=None):
     return pool.to(device=dev, dtype=dtype)
 
 
-def _run_g2(name, dtype):
+def _run_g2(name, dtype, share_prep=True):
     g = load_npz(name)
     dev = _dev()
     B = int(g["B"])
     pool = _build_pool(g, dtype)
+    pool.options.share_prep = share_prep
     pool.train()
     x = t(g["x"]).to(dev, dtype).requires_grad_(True)
     q0 = t(g["query"]).to(dev, dtype).requires_grad_(True)
@@ -211,12 +212,9 @@ def test_hilo_weight_gradients_are_float32_accurate(case):
     pool = _build_pool(d, torch.float32).train()              # float32 master parameters: float32-stored gradients
     x = t(d["x"]).to(dev, torch.bfloat16).requires_grad_(True)
     q0 = t(d["query"]).to(dev, torch.bfloat16).requires_grad_(True)
-    layer._HILO_GRADS = True
-    try:
-        y, info = pool(q0.expand(B, -1, -1), x, return_info=True)
-        ((y.float() * t(d["dy"]).to(dev)).sum() + (info["attention_weights"].float() * t(d["dwbar"]).to(dev)).sum()).backward()
-    finally:
-        layer._HILO_GRADS = False
+    assert pool.options.hilo_grads is None                    # the default: on by itself for float32-stored gradients
+    y, info = pool(q0.expand(B, -1, -1), x, return_info=True)
+    ((y.float() * t(d["dy"]).to(dev)).sum() + (info["attention_weights"].float() * t(d["dwbar"]).to(dev)).sum()).backward()
     a = pool.attention
     got = dict(dw_in=a.in_proj_weight.grad, db_in=a.in_proj_bias.grad, dw_out=a.out_proj.weight.grad, db_out=a.out_proj.bias.grad)
     errs = {k: rel_err(v.detach().float().cpu(), truth[k]) for k, v in got.items()}
@@ -723,15 +721,12 @@ def test_empty_batch_matches_reference_contract():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_shared_preparation_equals_backward_own_preparation(dtype, monkeypatch):
+def test_shared_preparation_equals_backward_own_preparation(dtype):
     """aecf_pool_fwd_args.saved_prep: the backward fed by the forward's preparation launch returns the same bits as
     the backward that prepares its own operands (include/aecf_hip.h, ABI v3)."""
-    import aecf_amd.layer as layer
     name = (BF16_CASES if dtype == torch.bfloat16 else FP32_CASES)[0]
-    monkeypatch.setattr(layer, "_SHARE_PREP", True)
-    _, shared = _run_g2(name, dtype)
-    monkeypatch.setattr(layer, "_SHARE_PREP", False)
-    _, own = _run_g2(name, dtype)
+    _, shared = _run_g2(name, dtype, share_prep=True)
+    _, own = _run_g2(name, dtype, share_prep=False)
     for k in shared:
         assert torch.equal(shared[k], own[k]), k
 
@@ -801,14 +796,104 @@ def test_in_kernel_uniforms_equal_torch_rand(n):
     want = torch.rand(n, device=dev)
     after_torch = gen.get_offset()
     gen.set_offset(start)
-    seed, offset, threads = _philox_draw(n, dev)
+    seed, offset, threads, _ = _philox_draw(n, dev)
     assert offset == start and gen.get_offset() == after_torch, (start, after_torch, gen.get_offset())
     got = torch.empty(n, device=dev)
-    _lib.check(_lib.load().aecf_philox_uniforms(n, seed, offset, threads, _ptr(got), _stream()), "aecf_philox_uniforms")
+    _lib.check(_lib.load().aecf_philox_uniforms(n, seed, offset, threads, 0, _ptr(got), _stream()), "aecf_philox_uniforms")
     torch.cuda.synchronize()
     bad = (got != want).nonzero()
     assert bad.numel() == 0, (int(bad.numel()), bad[:4].flatten().tolist(), got[bad[:4]].flatten().tolist(),
                               want[bad[:4]].flatten().tolist(), threads)
+
+
+@pytest.mark.parametrize("n,lo,hi", [(3000, 1000, 2500), (524288 + 77, 300000, 524288 + 77), (2100000, 7, 1300001)])
+def test_in_kernel_draw_of_a_shard_equals_the_global_tensor(n, lo, hi):
+    """ABI v9 (philox_element0): elements [lo, hi) of the draw torch.rand(n) evaluated on their own -- what a data-parallel rank
+    does for its rows of the global batch -- are the global tensor's elements, below and beyond one grid-stride iteration."""
+    from aecf_amd import _lib
+    from aecf_amd.layer import _philox_draw, _ptr, _stream
+    dev = _dev()
+    torch.cuda.manual_seed(99 + n)
+    gen = torch.cuda.default_generators[dev.index or 0]
+    start = gen.get_offset()
+    want = torch.rand(n, device=dev)
+    end = gen.get_offset()
+    gen.set_offset(start)
+    seed, offset, threads, elem0 = _philox_draw(n, dev, None, lo)
+    assert elem0 == lo and gen.get_offset() == end            # the generator advances as the GLOBAL call does
+    got = torch.empty(hi - lo, device=dev)
+    _lib.check(_lib.load().aecf_philox_uniforms(hi - lo, seed, offset, threads, lo, _ptr(got), _stream()), "aecf_philox_uniforms")
+    assert torch.equal(got, want[lo:hi])
+
+
+@pytest.mark.parametrize("dtype,B,M,E,H", [(torch.bfloat16, 6000, 3, 512, 8), (torch.float32, 900, 4, 128, 4)])
+def test_batch_shards_draw_their_rows_of_one_global_draw(dtype, B, M, E, H):
+    """pool(..., batch_shard=(first_row, global_batch)): three uneven shards, each seeded like the full-batch call, see the
+    full batch's masks row for row (outputs, weights, entropies bit-equal) and leave the generator where the full call leaves it."""
+    import aecf_amd
+    dev = _dev()
+    torch.manual_seed(B)
+    query, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=0.4, num_heads=H)
+    pool = pool.to(dev, dtype).train()
+    query = query.detach().to(dev, dtype)
+    x = (torch.randn(B, M, E, device=dev) * torch.linspace(0.5, 3.0, M, device=dev).view(1, M, 1)).to(dtype)
+    gen = torch.cuda.default_generators[dev.index or 0]
+    torch.cuda.manual_seed(31)
+    out, info = pool(query.expand(B, -1, -1), x, return_info=True)
+    end = gen.get_offset()
+    assert 0.05 < float(info["mask_rate"].float().mean()) < 0.95
+    for lo, hi in ((0, B // 6), (B // 6, B - 333), (B - 333, B)):
+        torch.cuda.manual_seed(31)
+        o_s, i_s = pool(query.expand(hi - lo, -1, -1), x[lo:hi], return_info=True, batch_shard=(lo, B))
+        assert gen.get_offset() == end
+        assert torch.equal(o_s, out[lo:hi])
+        for k in ("masked_attention_weights", "mask_rate", "entropy", "attention_weights"):
+            assert torch.equal(i_s[k], info[k][lo:hi]), (k, lo, hi)
+        # the tensor path of the same shard (what runs inside a graph capture): the same rows of the same global tensor
+        torch.cuda.manual_seed(31)
+        pool.options.draw_in_kernel = False
+        try:
+            o_t, i_t = pool(query.expand(hi - lo, -1, -1), x[lo:hi], return_info=True, batch_shard=(lo, B))
+        finally:
+            pool.options.draw_in_kernel = True
+        assert gen.get_offset() == end and torch.equal(i_t["masked_attention_weights"], i_s["masked_attention_weights"])
+    with pytest.raises(ValueError):
+        pool(query.expand(10, -1, -1), x[:10], batch_shard=(B - 5, B))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grad_scale_is_folded_into_the_stored_gradients(dtype):
+    """aecf_pool_bwd_args.grad_scale (ABI v9; dp.attach passes 1 / world): the five parameter gradients come out multiplied by
+    it -- exactly, for a power of two -- and dx does not."""
+    import aecf_amd
+    from aecf_amd import layer
+    dev = _dev()
+    B, M, E, H = 700, 3, 256, 4
+    torch.manual_seed(5)
+    query, pool = aecf_amd.create_fusion_pool(E, M, mask_prob=0.3, num_heads=H)
+    pool = pool.to(dev, dtype).train()
+    q = torch.nn.Parameter(query.detach().to(dev, dtype))
+    x = torch.randn(B, M, E, device=dev).to(dtype)
+    dy = torch.randn(B, 1, E, device=dev).to(dtype)
+    u = torch.rand(B, 1, M, device=dev)
+    params = [q] + list(pool.parameters())
+
+    def run():
+        for p_ in params:
+            p_.grad = None
+        xs = x.clone().requires_grad_(True)
+        out, info = pool(q.expand(B, -1, -1), xs, return_info=True, uniforms=u)
+        torch.autograd.backward([out, info["attention_weights"]], [dy, torch.ones_like(info["attention_weights"]) * 0.01])
+        return xs.grad.clone(), [p_.grad.clone() for p_ in params]
+    dx0, g0 = run()
+    pool.options.dp = layer.DpState(world=4, grad_scale=0.25, keep_f32=False)
+    try:
+        dx1, g1 = run()
+    finally:
+        pool.options.dp = None
+    assert torch.equal(dx0, dx1)
+    for a_, b_ in zip(g0, g1):
+        assert torch.equal((a_.float() * 0.25).to(dtype), b_), tuple(a_.shape)
 
 
 @pytest.mark.parametrize("dtype,B,M,E,H", [(torch.bfloat16, 5000, 3, 512, 8), (torch.float32, 700, 4, 128, 4),
@@ -829,11 +914,11 @@ def test_masks_drawn_in_the_kernel_equal_the_tensor_path(dtype, B, M, E, H):
     out_k, info_k = pool(query.expand(B, -1, -1), x, return_info=True)
     off_k = gen.get_offset()
     torch.cuda.manual_seed(99)
-    layer._DRAW_IN_KERNEL = False
+    pool.options.draw_in_kernel = False
     try:
         out_t, info_t = pool(query.expand(B, -1, -1), x, return_info=True)
     finally:
-        layer._DRAW_IN_KERNEL = True
+        pool.options.draw_in_kernel = True
     assert gen.get_offset() == off_k
     torch.cuda.manual_seed(99)
     u = torch.rand(B, 1, M, device=dev)

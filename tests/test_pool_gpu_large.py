@@ -125,10 +125,16 @@ def test_full_size_bf16(name):
     errs = {k: rel_err(c(ch[k]), b[k2]) for k, k2 in (("dw_in", "dw_in"), ("db_in", "db_in"), ("dw_out", "dw_out"),
                                                       ("db_out", "db_out"))}
     errs["dq"] = rel_err(c(ch["dq"]), b["dquery"].sum(0, keepdim=True))
-    # the bf16 kernels feed derived operands (dy W_o, the pooled rows) to the MFMA rounded to bf16 once each:
-    # measured 1.5-2.1e-3 at these sizes (torch's own bf16 path: 4.4-6.3e-3)
+    # float32-STORED gradients (float32 master parameters).  Where the hi + lo weight-gradient products are built (d = 256 /
+    # 512, M <= 3: on by themselves for such parameters, layer.PoolOptions.hilo_grads) they meet north_star's 1e-3 with room to
+    # spare -- asserted at 1e-4, measured 3-5e-6; dq is handed back through the bf16 query and carries that rounding.  Other
+    # shapes feed the derived operands (dy W_o, the pooled rows) to the MFMA rounded to bf16 once each: measured 1.5-2.1e-3
+    # (torch's own bf16 path: 4.4-6.3e-3)
+    import ctypes
+    from aecf_amd import _lib
+    hilo = _lib.load().aecf_pool_hilo_bwd_workspace_bytes(ctypes.byref(_lib.PoolDesc(chunk, M, E, H, _lib.AECF_BF16, 1, 1, 0.15, 0.7, 1e-8))) > 0
     for k, e in errs.items():
-        assert e < 3e-3, (k, e)
+        assert e < (1e-4 if (hilo and k != "dq") else 3e-3), (k, e, hilo)
 
 
 def test_full_size_bf16_parameters_c2():
@@ -144,6 +150,7 @@ def test_full_size_bf16_parameters_c2():
     for k in ("dw_in", "db_in", "dw_out", "db_out", "dq"):
         assert full[k].dtype == dt, k
     master_pool, master_q, *_ = _setup("c2", dt, param_dtype=torch.float32)
+    master_pool.options.hilo_grads = False                         # the SAME products (the default for float32 masters is hi + lo)
     master = _run(master_pool, master_q, x, dy, U, dt)
     for k in ("y", "w", "mw", "ent", "rate", "dx"):
         assert torch.equal(master[k], full[k]), k

@@ -23,12 +23,12 @@ b = O.mha_backward(qe, d["x"], d["x"], d["w_in"], d["b_in"], d["w_out"], H, f, d
 
 
 def run(hilo):
-    layer._HILO_GRADS = hilo
     pool = aecf_amd.MultimodalAttentionPool(E, num_heads=H)
     with torch.no_grad():
         pool.attention.in_proj_weight.copy_(d["w_in"]); pool.attention.in_proj_bias.copy_(d["b_in"])
         pool.attention.out_proj.weight.copy_(d["w_out"]); pool.attention.out_proj.bias.copy_(d["b_out"])
     pool = pool.to(dev).train()                        # float32 master parameters, bf16 activations
+    pool.options.hilo_grads = hilo
     x = d["x"].to(dev, torch.bfloat16).requires_grad_(True)
     q0 = d["query"].to(dev).requires_grad_(True)
     y, info = pool(q0.to(torch.bfloat16).expand(B, -1, -1), x, return_info=True)
@@ -47,4 +47,3 @@ def run(hilo):
 
 for hilo in (False, True):
     print("hilo" if hilo else "default", run(hilo), flush=True)
-layer._HILO_GRADS = False

@@ -17,7 +17,7 @@ for B in (8192, 16384, 32768, 65536, 131072):
         bench.step(pool, query, x, dy, params, False)
     st = bench.StageTimer()
     for _ in range(30):
-        st.arm(); bench.step(pool, query, x, dy, params, False); st.disarm()
+        st.arm(pool); bench.step(pool, query, x, dy, params, False); st.disarm(pool)
         torch.cuda.synchronize(); st.collect()
     res[B] = st.median_ms()
     del pool, query, x, dy, params

@@ -18,10 +18,10 @@
 // the pooled product also has a 1024-thread form with a 256 x 128 tile (gemm_tn_tr_wide_kernel below), used when it fits.
 // Output: float32 partial slabs per batch split (deterministic; reduced by reduce_segments).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "aecf_kernels.h"
 #include "aecf_tile.h"
-#include "aecf_tr_tile.h"
 
 namespace aecf {
 
@@ -29,6 +29,13 @@ namespace {
 
 constexpr int TRB = 64;                        // batch rows per step
 constexpr int TR_TILE = TRB * 256;             // bytes of one [64][128 bf16] tile
+
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+
+__device__ __forceinline__ int tr_off(int row, int ch) {
+    return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
 
 // LDS-DMA of a [64 rows][256 B] tile.  The DMA destination is lane-linear: chunk c = tid + 512 i lands at byte 16 c,
 // which in this image is row 8 (c >> 7) + ((c >> 2) & 7), chunk 4 ((c >> 5) & 3) + ((c & 3) ^ ((row >> 2) & 3)): the
@@ -63,6 +70,14 @@ __device__ __forceinline__ void dma_tile_tr_async(const char* __restrict__ src, 
 // -- one register broadcast to both halves through op_sel -- gave run-to-run different low halves on MI355X at full
 // size (profiles/r01_pmc_notes.md); this file is built with -fno-slp-vectorize and the full-size determinism test
 // (tests/test_pool_gpu_large.py) guards the pair form.
+// MFMA operand (8 consecutive batch rows 32 ks + 8 lg .. + 7 of feature column col0 + r16) by two transposed reads
+__device__ __forceinline__ u32x4 tr_frag(const char* tile, int addr_lo, int addr_hi) {
+    const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(tile + addr_lo));
+    const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(tile + addr_hi));
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l[0], l[1], h[0], h[1]};
+}
+
 template <int M_, bool POOLED, int MAXS>
 __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(GemmTnArgs p) {
     using X = Tr<BF16>;
@@ -256,25 +271,35 @@ __global__ __launch_bounds__(512, (M_ <= 3 ? 4 : 2)) void gemm_tn_tr_kernel(Gemm
                     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[m][i]));
                 if (more) load_x(base + TRB, c);          // the chunk registers are free again: next step's chunk flies
                 const int woff = tr_off(prow, pc + 8 * c);
+                auto pool_slots = [&](auto lo_tag) {              // (two copies, one branch: see gemm_tn_tr_wide_kernel)
+                    constexpr bool LO = decltype(lo_tag)::value;
 #pragma unroll
-                for (int sl = 0; sl < MAXS; ++sl) {
-                    if (sl < nslots) {
-                        f32x2 pv[4];
-                        const f32x2 p0 = plc[sl * M_];
+                    for (int sl = 0; sl < MAXS; ++sl) {
+                        if (sl < nslots) {
+                            f32x2 pv[4];
+                            const f32x2 p0 = plc[sl * M_];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pv[i] = xv[0][i] * p0;
+                            for (int i = 0; i < 4; ++i) pv[i] = xv[0][i] * p0;
 #pragma unroll
-                        for (int m = 1; m < M_; ++m) {
-                            const f32x2 pm = plc[sl * M_ + m];
+                            for (int m = 1; m < M_; ++m) {
+                                const f32x2 pm = plc[sl * M_ + m];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) pv[i] = __builtin_elementwise_fma(xv[m][i], pm, pv[i]);
+                                for (int i = 0; i < 4; ++i) pv[i] = __builtin_elementwise_fma(xv[m][i], pm, pv[i]);
+                            }
+                            u32x4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (LO) {                          // the low parts of the pooled values (AECF_HILO_GRADS)
+                                    pv[i][0] -= X::to_f32(X::from_f32(pv[i][0]));
+                                    pv[i][1] -= X::to_f32(X::from_f32(pv[i][1]));
+                                }
+                                o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                            }
+                            *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
                         }
-                        u32x4 o;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
-                        *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
                     }
-                }
+                };
+                if (p.pool_lo) pool_slots(std::true_type()); else pool_slots(std::false_type());
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                 // pooled tiles visible
@@ -345,6 +370,14 @@ __device__ __forceinline__ void dma_subtile_1024(const char* __restrict__ src, u
 }
 #pragma clang diagnostic pop
 
+#ifdef AECF_TN_TIMELINE
+// experiment build only (tools/debug/tn_timeline.py): shader-clock stamps of one wave at the phase boundaries of every step
+__device__ unsigned long long g_tn_timeline[8 * 64 * 8];
+#define TN_STAMP(slot) do { if (tl_on) { tl[(step_no * 8 + (slot))] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define TN_STAMP(slot) do { } while (0)
+#endif
+
 template <int M_, int MAXS>
 __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) {
     using X = Tr<BF16>;
@@ -356,6 +389,14 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
     const int EJ = p.Ej > 0 ? p.Ej : p.E;
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
     if (p.dq.w_k) dqp_rows<BF16>(p.dq, (int)blockIdx.x, (int)gridDim.x);      // side job: dq' for the finalize launch (aecf_common.h)
+#ifdef AECF_TN_TIMELINE
+    // waves 0, 5, 10, 15 of blocks 0 and 300 (lane 0)
+    const int tl_wsel = (w % 5 == 0) ? w / 5 : -1;
+    const int tl_bsel = blockIdx.x == 0 ? 0 : (blockIdx.x == 300 ? 1 : -1);
+    const bool tl_on = lane == 0 && tl_wsel >= 0 && tl_bsel >= 0;
+    unsigned long long* tl = g_tn_timeline + (tl_bsel * 4 + (tl_wsel < 0 ? 0 : tl_wsel)) * 64 * 8;
+    int step_no = 0;
+#endif
 
     const unsigned int nK = (unsigned)((E + 127) / 128), nJt = (unsigned)((EJ + 255) / 256);
     unsigned int split_u, tile_u;
@@ -491,7 +532,9 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
     auto do_step = [&](int64_t base, int cur) {
         const bool more1 = base + TRB < rend;
         const int nvalid_cur = (int)((rend - base) < TRB ? (rend - base) : TRB);
+        TN_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TN_STAMP(1);
 #pragma unroll
         for (int i = 0; i < PLN; ++i) {
             asm volatile("" : "+v"(plr[i]));
@@ -502,9 +545,13 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
 #pragma unroll
         for (int m = 0; m < M_; ++m) asm volatile("" : "+v"(Rb[m]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TN_STAMP(2);
         __builtin_amdgcn_s_barrier();                     // MFMAs of the previous step done; lhs tile + probabilities visible
+        TN_STAMP(3);
         if (more1) {
+#ifndef AECF_ABL_TN_NODMA
             issue_dma(base + TRB, cur ^ 1);
+#endif
             load_probs(base + TRB);
         }
         const f32x2* plc = pl + prow * (MAXS * M_);
@@ -518,33 +565,60 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_tr_wide_kernel(GemmTnArgs p) 
         for (int m = 0; m < M_; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[m][i]));
+#ifndef AECF_ABL_TN_NOX
         if (more1) load_x(base + TRB);                    // the chunk registers are free again: next step's chunk flies
+#endif
         const int woff = tr_off(prow, pc);
-        // straight-line code inside this phase (the phase every wave of the block waits for at the barrier below): a per-element
-        // test made hipcc emit 16 scalar branches here once (round 4: 105 -> 97 us without them)
+        // the slot loop in two copies picked by ONE branch per step: p.pool_lo tested per element made hipcc emit 16 branches and
+        // the dead subtract / convert chains inside this phase (the phase every wave of the block waits for at the barrier below)
+        auto pool_slots = [&](auto lo_tag) {
+            constexpr bool LO = decltype(lo_tag)::value;
 #pragma unroll
-        for (int sl = 0; sl < MAXS; ++sl) {
-            // M <= 3: every one of the MAXS slots, no test against nslots (a slot the tile does not have carries zero
-            // probabilities).  M = 4 keeps the test: without it the body spills at the 128-VGPR cap
-            if (M_ >= 4 && sl >= nslots) continue;
-            f32x2 pv[4];
-            const f32x2 p0 = plc[sl * M_];
+            for (int sl = 0; sl < MAXS; ++sl) {
+                // M <= 3: every one of the MAXS slots, no test against nslots (a slot the tile does not have carries zero
+                // probabilities): straight-line code.  M = 4 keeps the test: without it the body spills at the 128-VGPR cap
+                if (M_ >= 4 && sl >= nslots) continue;
+                f32x2 pv[4];
+                const f32x2 p0 = plc[sl * M_];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pv[i] = xv[0][i] * p0;
+                for (int i = 0; i < 4; ++i) pv[i] = xv[0][i] * p0;
 #pragma unroll
-            for (int m = 1; m < M_; ++m) {
-                const f32x2 pm = plc[sl * M_ + m];
+                for (int m = 1; m < M_; ++m) {
+                    const f32x2 pm = plc[sl * M_ + m];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pv[i] = __builtin_elementwise_fma(xv[m][i], pm, pv[i]);
+                    for (int i = 0; i < 4; ++i) pv[i] = __builtin_elementwise_fma(xv[m][i], pm, pv[i]);
+                }
+                u32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (LO) {                                      // the low parts of the pooled values (AECF_HILO_GRADS)
+                        pv[i][0] -= X::to_f32(X::from_f32(pv[i][0]));
+                        pv[i][1] -= X::to_f32(X::from_f32(pv[i][1]));
+                    }
+                    o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
+                }
+                *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
             }
-            u32x4 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(pv[i][0], pv[i][1]);
-            *reinterpret_cast<u32x4*>(ldsR + sl * TR_TILE + woff) = o;
+        };
+#ifdef AECF_ABL_TN_NOPOOL
+        if (base == rbeg)
+#endif
+        {
+            if (p.pool_lo) pool_slots(std::true_type()); else pool_slots(std::false_type());
         }
+        TN_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TN_STAMP(5);
         __builtin_amdgcn_s_barrier();                     // pooled tiles visible
+        TN_STAMP(6);
+#ifdef AECF_ABL_TN_NOMMA
+        if (base == rbeg)
+#endif
         mma_phase(cur, nvalid_cur);
+        TN_STAMP(7);
+#ifdef AECF_TN_TIMELINE
+        ++step_no;
+#endif
     };
 
     if (rbeg < rend) {
@@ -716,11 +790,15 @@ __global__ __launch_bounds__(64 * NW) void u_mfma_kernel(GemmTnArgs p) {
     }
 }
 
+#ifndef AECF_UNW
+#define AECF_UNW 0
+#endif
 bool u_mfma_supported(const GemmTnArgs& a) { return a.H <= 8 && a.E % 128 == 0 && a.M >= 1 && a.u_splits > 0; }
 
 // block width: 32 columns per wave; the widest block whose columns tile E (each x row is then read in the fewest pieces)
 void launch_u_mfma(const GemmTnArgs& a, hipStream_t s) {
-    const int nw = a.E % 512 == 0 ? 16 : (a.E % 256 == 0 ? 8 : 4);
+    int nw = AECF_UNW;
+    if (nw == 0) nw = a.E % 512 == 0 ? 16 : (a.E % 256 == 0 ? 8 : 4);
     dim3 grid((unsigned)(a.E / (32 * nw)), (unsigned)a.u_splits);
     const size_t smem = (size_t)3 * 32 * 64 * nw + (size_t)2 * 16 * 40 * 2;
     if (nw == 16) {
@@ -777,3 +855,9 @@ void launch_gemm_tn_tr(const GemmTnArgs& a, hipStream_t s) {
 }
 
 }  // namespace aecf
+
+#ifdef AECF_TN_TIMELINE
+extern "C" int aecf_debug_tn_timeline(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(aecf::g_tn_timeline), sizeof(unsigned long long) * (size_t)n);
+}
+#endif

@@ -23,20 +23,45 @@
 #include "aecf_kernels.h"
 #include "aecf_tile.h"
 
+// experiment switches (tools/build_variant.sh): LDS operand reads issued this many items ahead of their MFMAs
+#ifndef AECF_WS_PF
+#define AECF_WS_PF 3
+#endif
+#ifndef AECF_VPROJ_PF
+#define AECF_VPROJ_PF 3
+#endif
+#ifndef AECF_DX_PF
+#define AECF_DX_PF 3
+#endif
+#ifndef AECF_VPROJ_SPREAD
+#define AECF_VPROJ_SPREAD 0
+#endif
+
 namespace aecf {
 
 namespace {
 
 enum { WS_PLAIN = 0, WS_VPROJ = 1, WS_VFLAT = 2 };
 
-// LDS operand reads are issued this many items ahead of their MFMAs (depths 2 and 5 measured level, profiles/r04_c2_*_ablation.txt)
-constexpr int WS_PF = 3, VPROJ_PF = 3, DX_PF = 3;
+#ifdef AECF_WS_TIMELINE
+// experiment build only (tools/debug/ws_timeline.py): shader-clock stamps of a few waves at the phase boundaries of every step
+// (a stamp costs ~150 cycles and drains lgkmcnt: compare phases between waves and builds, not against the untimed kernel)
+__device__ unsigned long long g_ws_timeline[2 * 8 * 64 * 8]      /* [kernel: 0 vproj_slab, 1 dsu_ws][8 waves][64 steps][8 stamps] */;
+#define WS_STAMP(slot) do { if (tl_on && step_no < 64) tl[step_no * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_STAMP(slot) do { } while (0)
+#endif
 
-// LDS tiles of gemm_ws_kernel: two.  (A third tile for the plain form -- copy two steps ahead -- measured neutral at C2, 38 us
-// either way, profiles/r04_c2_plain_ablation.txt: copy, stores and MFMA + operand reads each take ~19 us on their own and
-// already overlap.  The phase-ablation and in-kernel timeline builds these numbers came from are kept out of the product
-// source: tools/micro/variants/.)
-constexpr int ws_plain_bufs(int, int) { return 2; }
+
+#ifndef AECF_WS_PLAIN_BUFS
+#define AECF_WS_PLAIN_BUFS 2
+#endif
+// LDS tiles of gemm_ws_kernel.  -DAECF_WS_PLAIN_BUFS=3 gives the plain form a third tile (copy two steps ahead); measured
+// neutral at C2 (38 us either way, profiles/r04_c2_plain_ablation.txt: copy, stores and MFMA + operand reads each take ~19 us
+// on their own and already overlap), so the default stays at two
+constexpr int ws_plain_bufs(int mode, int kt) {
+    return (mode == WS_PLAIN && AECF_WS_PLAIN_BUFS == 3 && 3 * 32 * 64 * kt <= 150 * 1024) ? 3 : 2;
+}
 
 // copy NROWS rows (K bf16 each) to an LDS tile; row r's physical chunk p holds logical chunk p ^ key(r),
 // key(r) = (r / KEYDIV) & 15.  Rows >= rows_valid re-read the last valid row (their outputs are never stored).
@@ -274,8 +299,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
         // a step of 64 MFMAs per wave is shorter than one HBM round trip under load, so one step of lead left the wait at the
         // end of every step exposed
         const bool two_ahead = NBUF == 3 && o0 + 2 * OROWS < o_end;
+#ifdef AECF_ABL_PL_NODMA
+        if (MODE != WS_PLAIN) { if (!GATE && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1); }
+#else
         if (NBUF == 3) { if (two_ahead) issue(o0 + 2 * OROWS, cur >= 1 ? cur - 1 : 2); }
         else if (!GATE && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);
+#endif
         if (o0 + OROWS < o_end) load_probs(o0 + OROWS, pm_next);
 
         if (GATE) {
@@ -328,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
         //      The operand reads run PF items ahead of the MFMAs (a ring of PF+1 registers sets, pinned with
         //      sched_group_barrier so the compiler keeps the reads early instead of sinking them next to their use).
         constexpr int NIT = RT * KT;
-        constexpr int PF = WS_PF;
+        constexpr int PF = AECF_WS_PF;
         const char* tb = smem + cur * TILE;
         auto rd = [&](int i) -> u32x4 {
             const int ks = PL ? i / RT : i % KT;
@@ -357,6 +386,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
             if (GATE && i == NIT / 8 && o0 + OROWS < o_end) issue(o0 + OROWS, cur ^ 1);   // 7/8 of the MFMA phase to land in
             const int ks = PL ? i / RT : i % KT;
             const int t = PL ? i % RT : 0;
+#ifdef AECF_ABL_PL_NOMMA
+            if (MODE == WS_PLAIN) { if (i % 16 == 0) for (int c = 0; c < CT; ++c) acc[t][c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[t][c]);
+                                    else asm volatile("" :: "v"(xf[i % (PF + 1)])); } else
+#endif
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[t][c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[t][c]);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
@@ -407,6 +440,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(GemmNtArgs p, int rows_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * c + r] = acc[t][c][r] + bias[4 * c + r];
                 if (!VF) {
+#ifdef AECF_ABL_PL_NOSTORE
+                    for (int j = 0; j < NV; ++j) asm volatile("" :: "v"(v[j]));
+                    if (false)
+#endif
                     if (row < o_end) {
                         if (p.out_f32) store_cols_f32<CT>(reinterpret_cast<float*>(p.c) + row * N + ncol0 + NV * lg, v);
                         else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + row * N + ncol0 + NV * lg, v);
@@ -593,7 +630,9 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
     for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // do rows + stage of this step visible
+#ifndef AECF_ABL_DX_NOSTAGE
         if (o0 + 16 < o_end) load_stage(o0 + 16);                  // (the rows' copy is issued behind the first head's MFMAs, below)
+#endif
         const char* tb = raw + cur * RAW;
         const float* sp = stage + cur * 16 * HMS + r16 * HMS;      // this lane's sample: probs[h][m]
         const char* xq = xtra + cur * XT + r16 * M_ * XROWB + 16 * lg;
@@ -614,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             }
 
         // value-side term, head by head; operand reads run PF K-steps ahead
-        constexpr int PF = DX_PF;
+        constexpr int PF = AECF_DX_PF;
         auto rd = [&](int ks) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(tb + xaddr[ks & 3] + (ks >> 2) * 256);
         };
@@ -636,10 +675,17 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
             }
         };
         head_mma(0, Pc);
+#ifndef AECF_ABL_DX_NODMA
         if (o0 + 16 < o_end) issue(o0 + 16, cur ^ 1);
+#endif
 #pragma unroll
         for (int h = 0; h < H_; ++h) {
             if (h + 1 < H_) head_mma(h + 1, Pn);
+#ifdef AECF_ABL_DX_NOWEIGHT
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[h % M_][c] += Pc[c];
+            if (false)
+#endif
 #pragma unroll
             for (int m = 0; m < M_; ++m) {
                 const float a = sp[h * M_ + m];
@@ -660,11 +706,20 @@ __global__ __launch_bounds__(512, 2) void dx_ws2_kernel(BwdGArgs p, int rows_per
         }
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next do rows + stage values landed
+#ifndef AECF_ABL_DX_NOSTAGE
         if (o0 + 16 < o_end) park_stage(cur ^ 1);                  // the other buffer: nobody reads it during this step
+#endif
         // (round 4, measured and dropped: the step's stores -- 16 of this kernel's 78 us by ablation, profiles/r04_c2_dx_ablation.txt --
         //  packed and issued one at a time behind the NEXT step's first heads' MFMAs, with and without a mask branch around
         //  them: 91-94 us against 76-80 -- a store inside the head pipeline costs more than eight waves storing at once here)
         const int64_t b = o0 + r16;
+#ifdef AECF_ABL_DX_NOSTORE
+#pragma unroll
+        for (int m = 0; m < M_; ++m)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) asm volatile("" :: "v"(acc[m][c]));
+        if (false)
+#endif
         if (b < o_end) {
 #pragma unroll
             for (int m = 0; m < M_; ++m) {
@@ -835,9 +890,18 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef AECF_WS_TIMELINE
+    const int tl_wsel = (w % 2 == 0) ? w / 2 : -1;                 // waves 0, 2, 4, 6 of blocks 0 and 133
+    const int tl_bsel = blockIdx.x == 0 ? 0 : (blockIdx.x == 133 ? 1 : -1);
+    const bool tl_on = lane == 0 && tl_wsel >= 0 && tl_bsel >= 0;
+    unsigned long long* tl = g_ws_timeline + (8 + tl_bsel * 4 + (tl_wsel < 0 ? 0 : tl_wsel)) * 64 * 8;
+    int step_no = 0;
+#endif
     int cur = 0;
     for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
+        WS_STAMP(0);
         __builtin_amdgcn_s_barrier();                              // this step's tiles visible; the other buffers free
+        WS_STAMP(1);
         if (o0 + 16 < o_end) {
             issue(o0 + 16, cur ^ 1);
             load_stats(o0 + 16, pmv_n, dwb_n);
@@ -948,8 +1012,10 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 }
             }
         }
+        WS_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        WS_STAMP(3);
         asm volatile("" : "+v"(pmv), "+v"(dwb));
         if (w < HBL) {                               // whole waves: the lane-group sum below needs every lane
             float da = 0.f;
@@ -979,8 +1045,10 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 dsl[ds_hh * DSROW + kslot(ds_s, ds_m)] = X::from_f32(d - X::to_f32(hi));
             }
         }
+        WS_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        WS_STAMP(5);
         // u^T[k, h] += x^T[k, (b,m)] ds[(b,m), h]:  A operand by transposed reads of the x tile (rows = K index)
 #pragma unroll
         for (int ks = 0; ks < KU; ++ks) {
@@ -994,7 +1062,12 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
                 uacc[ct] = X::mma(af, bl, uacc[ct]);
             }
         }
+        WS_STAMP(6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tiles and statistics landed (a whole step to do so)
+        WS_STAMP(7);
+#ifdef AECF_WS_TIMELINE
+        ++step_no;
+#endif
         asm volatile("" : "+v"(pmv_n), "+v"(dwb_n));
         pmv = pmv_n; dwb = dwb_n;
     }
@@ -1181,6 +1254,25 @@ __global__ __launch_bounds__(512, 2) void dsu_slab_kernel(BwdGArgs p, float* __r
         // (the slab's NDMA = 2 M pieces go out one per (head group, modality) pass of phase 1 below: a copy instruction costs its
         //  wave 100-200 issue cycles -- seven in a row at the top of the step were ~1000 cycles in front of the first MFMA)
         if (more) load_stats(o0 + 16, pmv_n, dwb_n);
+#ifdef AECF_ABL_DSU_WSTREAM
+        // TIMING-ONLY emulation of a fused dout -> dscore kernel ("do never exists in HBM"): the block would
+        // form do_h = dy W_o^T[:, its 256 columns] itself, i.e. stream its 256 KB slice of W_o^T through LDS every 16-sample
+        // step (the register file holds W_v^T).  Here AECF_ABL_DSU_WSTREAM 1 KB pieces per wave and step (32 = the full slice)
+        // are copied from the L2-resident weights into a scratch slot and never read: the copies' cost alone, without the 32
+        // extra MFMAs per wave and step the product itself would add.
+        {
+            const char* wsrc_b = reinterpret_cast<const char*>(p.wvt) + (size_t)w * 32768;
+#pragma unroll 4
+            for (int i = 0; i < AECF_ABL_DSU_WSTREAM; ++i) {
+                const unsigned int voff = (unsigned)(i * 1024 + lane * 16);
+                const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(reinterpret_cast<char*>(dsw) + 8 * 2 * 4 * 72 * 2 + w * 1024);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(wsrc_b), "s"(dst) : "memory", "m0");
+#pragma clang diagnostic pop
+            }
+        }
+#endif
         // ---- phase 1: P_h by MFMA, dot with this lane's x values, partial dots to LDS
         const char* tb = db + dcur * DT;
         const char* xs = xb + cur * XT;
@@ -1202,10 +1294,19 @@ __global__ __launch_bounds__(512, 2) void dsu_slab_kernel(BwdGArgs p, float* __r
             }
 #pragma unroll
             for (int m = 0; m < M_; ++m) {
+#ifndef AECF_ABL_DSU_NOX
                 if (more) issue_x_piece(o0 + 16, cur ^ 1, (h0 / HG) * M_ + m);
+#endif
                 float a[HG];
 #pragma unroll
                 for (int g = 0; g < HG; ++g) a[g] = 0.f;
+#ifdef AECF_ABL_DSU_NODOT
+#pragma unroll
+                for (int g = 0; g < HG; ++g)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) a[g] += P[g][ct][0] + P[g][ct][3];
+                if (false)
+#endif
 #pragma unroll
                 for (int c2 = 0; c2 < NCT / 2; ++c2) {
                     const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (xaddr0 ^ (64 * c2)) + m * 16 * SB);
@@ -1233,6 +1334,9 @@ __global__ __launch_bounds__(512, 2) void dsu_slab_kernel(BwdGArgs p, float* __r
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // ---- phase 2: softmax backward for (sample r16, head lg), all modalities in-lane; ds operands; u product
+#ifdef AECF_ABL_DSU_NODS
+        if (o0 == o_beg)
+#endif
         {
             const float* pr = part + cur * PT + (lg * 16 + r16) * 4;
             f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1267,6 +1371,9 @@ __global__ __launch_bounds__(512, 2) void dsu_slab_kernel(BwdGArgs p, float* __r
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's operand arrays are in LDS (its own reads follow)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef AECF_ABL_DSU_NOU
+        if (o0 == o_beg)
+#endif
 #pragma unroll
         for (int ks = 0; ks < KU; ++ks) {
             const u32x4 bh = *reinterpret_cast<const u32x4*>(smem + bh_off + 64 * ks);
@@ -1516,15 +1623,29 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
     for (int kg = 0; kg < KG; ++kg) asm volatile("" : "+v"(ga[kg][0]), "+v"(ga[kg][1]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // own slab of the first tile landed
     scores(0, gpart);
+#ifdef AECF_WS_TIMELINE
+    const int tl_wsel = (w % 2 == 1) ? w / 2 : -1;                 // waves 1, 3, 5, 7 of blocks 0 and 133
+    const int tl_bsel = blockIdx.x == 0 ? 0 : (blockIdx.x == 133 ? 1 : -1);
+    const bool tl_on = lane == 0 && tl_wsel >= 0 && tl_bsel >= 0;
+    unsigned long long* tl = g_ws_timeline + (tl_bsel * 4 + (tl_wsel < 0 ? 0 : tl_wsel)) * 64 * 8;
+    int step_no = 0;
+#endif
 
     int cur = 0;
     for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1) {
         const bool more = o0 + 16 < o_end;
+        WS_STAMP(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's partial scores of this step are in LDS
         __builtin_amdgcn_s_barrier();                              // tile and partials of this step visible; other buffers free
+        WS_STAMP(1);
         if (more) load_kp(o0 + 16);
         // ---- softmax over the modalities for (this wave's head, this lane's sample); partial sums in wave order
         float pm[M_];
+#ifdef AECF_ABL_NOSOFTMAX
+#pragma unroll
+        for (int m = 0; m < M_; ++m) pm[m] = 0.25f + 0.125f * m;
+        if (false)
+#endif
         {
             const float* gp = gpart + cur * GP;
             float mx = -INFINITY;
@@ -1546,12 +1667,18 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
                 for (int m = 0; m < M_; ++m) dst[m] = pm[m];
             }
         }
+        WS_STAMP(2);
         // ---- products: modality-major items, operand reads PF items ahead; the next tile's copy goes out among the first
-        constexpr int NIT = M_ * KT, PF = VPROJ_PF;
+        constexpr int NIT = M_ * KT, PF = AECF_VPROJ_PF;
         const char* tb = smem + cur * TILE;
         auto rd = [&](int i) -> u32x4 {
             const int ks = i % KT, m = i / KT;
+#ifdef AECF_ABL_NOLDSREAD
+            (void)tb;
+            return u32x4{(unsigned)(0x3f803f80u + ks), (unsigned)(0x3f803f80u + m), 0x3f803f80u, (unsigned)lane};
+#else
             return *reinterpret_cast<const u32x4*>(tb + (ks >> 1) * SLAB + m * 16 * SB + xoff[ks & 1]);
+#endif
         };
         f32x4 acc[CT];
 #pragma unroll
@@ -1567,7 +1694,15 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (i + PF < NIT) xf[(i + PF) % (PF + 1)] = rd(i + PF);
+#ifndef AECF_ABL_NODMA
+#if AECF_VPROJ_SPREAD > 0
+            // the slab's pieces one at a time, AECF_VPROJ_SPREAD items apart (a copy instruction costs its wave 100-200 issue cycles)
+            if (more && i >= NIT / 8 && (i - NIT / 8) % AECF_VPROJ_SPREAD == 0 && (i - NIT / 8) / AECF_VPROJ_SPREAD < NDMA)
+                issue_piece(o0 + 16, cur ^ 1, (i - NIT / 8) / AECF_VPROJ_SPREAD);
+#else
             if (i == NIT / 8 && more) issue(o0 + 16, cur ^ 1);
+#endif
+#endif
             const int ks = i % KT;
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[c] = X::mma(wreg[ks][c], xf[i % (PF + 1)], acc[c]);
@@ -1589,11 +1724,21 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
                 for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        WS_STAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slab of the next tile (and its mask bytes) landed
+        WS_STAMP(4);
 #pragma unroll
         for (int m = 0; m < M_; ++m) { asm volatile("" : "+v"(kp_next[m])); kp[m] = p.g_kpm ? kp_next[m] : 0u; }
+#ifndef AECF_ABL_NOSCORES
         if (more) scores(cur ^ 1, gpart + (cur ^ 1) * GP);         // next step's partial scores, from this wave's own slab
+#endif
+        WS_STAMP(5);
         const int64_t b = o0 + r16;
+#ifdef AECF_ABL_NOSTORE
+#pragma unroll
+        for (int j = 0; j < NV; ++j) asm volatile("" :: "v"(ov[j]));
+        if (false)
+#endif
         if (b < o_end) {
             if (p.v_out) {
 #pragma unroll
@@ -1604,6 +1749,10 @@ __global__ __launch_bounds__(512, 2) void vproj_slab_kernel(GemmNtArgs p, int ro
             else store_cols<CT>(reinterpret_cast<unsigned short*>(p.c) + b * N + ncol0 + NV * lg, ov);
             if (p.c_lo) store_cols_lo<CT>(reinterpret_cast<unsigned short*>(p.c_lo) + b * N + ncol0 + NV * lg, ov);
         }
+        WS_STAMP(6);
+#ifdef AECF_WS_TIMELINE
+        ++step_no;
+#endif
     }
 }
 
@@ -1773,3 +1922,8 @@ bool launch_dx_ws(const BwdGArgs& a, hipStream_t s) {
 
 }  // namespace aecf
 
+#ifdef AECF_WS_TIMELINE
+extern "C" int aecf_debug_ws_timeline(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(aecf::g_ws_timeline), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
