@@ -12,9 +12,10 @@
 //
 // Same tile images, transposed LDS reads (ds_read_b64_tr_b16), LDS-DMA and one-step-ahead operand fetches as
 // aecf_gemm_tn_tr.hip.  What differs is the step: 32 batch rows (one MFMA K-step) instead of 64, because a step now holds
-// twice the tiles -- wide form: lhs hi + lo [32][256] x 2 buffers = 64 KB, pooled hi + lo x 4 head slots = 64 KB.
+// twice the tiles -- pooled product: lhs hi + lo [32][128] x 2 buffers = 32 KB, pooled hi + lo x 2 head slots = 32 KB.
+// Measured at the headline shape (profiles/r05_c2_hilo_time.txt): dW_v 92 -> 152 us, dW_o 46 -> 75 us, against 310 / 107 us
+// for the round-4 launches; float32-stored parameter gradients 3 - 5e-6 of fp32 math.
 #include <stdlib.h>
-#include <type_traits>
 
 #include "aecf_kernels.h"
 #include "aecf_tile.h"
@@ -53,37 +54,39 @@ __device__ __forceinline__ void split_pack(float a, float b, unsigned int& hi, u
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dW_v: 1024 threads = 16 waves as 8 (j) x 2 (k), block tile 256 (j) x 128 (k), wave tile 32 x 64, ONE block per CU.
-// Pooling roles: thread = (half = t >> 9, row = (t >> 4) & 31, 16-byte chunk = t & 15); a half pools MAXS / 2 of the head slots
-// (both halves fetch the row's x chunks: the second fetch is an L1/L2 hit).
+// dW_v: 512 threads = 8 waves as 4 (j) x 2 (k), block tile 128 x 128, wave tile 32 x 64, TWO blocks per CU (64 KB of LDS each
+// at two head slots): the pooling phase of one block runs under the MFMA phase of the other.  (The 1024-thread 256 x 128 form
+// the default path prefers was built too: 165 us against 152 us at the headline shape -- with three MFMAs per fragment pair the
+// phases are long enough that overlapping them across blocks beats pooling each x slice once for four head slots.)  A thread
+// pools one 16-byte chunk of a row for every head slot of the tile.
 template <int M_, int MAXS>
-__global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p) {
+__global__ __launch_bounds__(512, 4) void gemm_tn_hilo_pooled_kernel(GemmTnArgs p) {
     using X = Tr<BF16>;
-    constexpr int RT = 2, CT = 4, SPH = MAXS / 2;
-    constexpr int NPL = HRB * MAXS * M_;                           // probabilities of a step (<= 1024: one per thread)
-    static_assert(NPL <= 1024 && MAXS % 2 == 0, "step shape");
+    constexpr int RT = 2, CT = 4;
+    constexpr int NPL = HRB * MAXS * M_;
+    static_assert(NPL <= 512, "step shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int E = p.E, H = p.H;
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
-    if (p.dq.w_k) dqp_rows<BF16>(p.dq, (int)blockIdx.x, (int)gridDim.x);      // side job: dq' for the finalize launch (aecf_common.h)
+    if (p.dq.w_k) dqp_rows<BF16>(p.dq, (int)blockIdx.x, (int)gridDim.x);
 
-    const unsigned int nK = (unsigned)(E / 128), nJt = (unsigned)(E / 256);
+    const unsigned int nK = (unsigned)(E / 128);
     unsigned int split_u, tile_u;
-    if (!xcd_tile(blockIdx.x, (unsigned)p.splits, nK * nJt, split_u, tile_u)) return;
+    if (!xcd_tile(blockIdx.x, (unsigned)p.splits, nK * nK, split_u, tile_u)) return;
     const int kt_idx = (int)(tile_u % nK), jt_idx = (int)(tile_u / nK);
-    const int j0 = jt_idx * 256, k0 = kt_idx * 128;
+    const int j0 = jt_idx * 128, k0 = kt_idx * 128;
     const int split = (int)split_u;
     const int64_t rbeg = (int64_t)split * p.rows_per_split;
     const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
 
     const int h_first = j0 / p.hd;
-    const int nslots = (j0 + 255) / p.hd - h_first + 1;
+    const int nslots = (j0 + 127) / p.hd - h_first + 1;
 
-    // LDS carve: lhs [2 buffers][hi, lo][2 sub-tiles] | pooled rhs [MAXS slots][hi, lo] | probabilities
+    // LDS carve: lhs [2 buffers][hi, lo] | pooled rhs [MAXS slots][hi, lo] | probabilities
     char* ldsL = smem;
-    char* ldsR = smem + 8 * HR_TILE;
-    f32x2* pl = reinterpret_cast<f32x2*>(ldsR + 2 * MAXS * HR_TILE);          // [HRB][MAXS][M] (p, p) pairs
+    char* ldsR = smem + 4 * HR_TILE;
+    f32x2* pl = reinterpret_cast<f32x2*>(ldsR + 2 * MAXS * HR_TILE);
 
     const int j0w = 32 * (w >> 1), k0w = 64 * (w & 1);
     const int wslot = (j0 + j0w) / p.hd - h_first;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
             tx[b1][hh] = 2048 * lg + 64 * q + 8 * (pp & 1) + 256 * hh + 16 * ((2 * b1 + (pp >> 1)) ^ (2 * (lg & 1) + hh));
-    const int a_org = (j0w >> 7) * HR_TILE + 512 * ((w >> 1) & 3);   // sub-tile, then lhs block 2 ((w >> 1) & 3) + rt
+    const int a_org = 512 * (w >> 1);
     const int b_org = 1024 * (w & 1);
 
     f32x4 acc[RT][CT];
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
     const unsigned int ldl = (unsigned)E * 2u;
     const unsigned int ldr = (unsigned)M_ * (unsigned)E * 2u;
 
-    const int half = threadIdx.x >> 9, prow = (threadIdx.x >> 4) & 31, pc = threadIdx.x & 15;
+    const int prow = threadIdx.x >> 4, pc = threadIdx.x & 15;
     const unsigned int prow_off = (unsigned)prow * ldr;
     u32x4 Rb[M_];
     float plr = 0.f;
@@ -122,10 +125,9 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
     auto issue_dma = [&](int64_t base, int buf) {
         const int nvalid = (int)((rend - base) < HRB ? (rend - base) : HRB);
         const int64_t off = base * (int64_t)ldl + (int64_t)j0 * 2;
-        dma_hr_images(lhs_hi + off, ldl, nvalid, ldsL + (4 * buf) * HR_TILE);
-        dma_hr_images(lhs_lo + off, ldl, nvalid, ldsL + (4 * buf + 2) * HR_TILE);
+        dma_hr_images(lhs_hi + off, ldl, nvalid, ldsL + (2 * buf) * HR_TILE);
+        dma_hr_images(lhs_lo + off, ldl, nvalid, ldsL + (2 * buf + 1) * HR_TILE);
     };
-    // probability (t, slot, m) of the step: thread idx = (t * MAXS + slot) * M + m
     const int pt = threadIdx.x / (MAXS * M_), prem = threadIdx.x - pt * (MAXS * M_);
     const int psl = prem / M_, pm = prem - psl * M_;
     auto probs_on = [&](int64_t base) -> bool {
@@ -148,43 +150,6 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(Rb[m]) : "v"(roff), "s"(xm) : "memory");
         }
     };
-    auto mma_phase = [&](int cur, int nvalid_cur) {
-        const char* lt = ldsL + 4 * cur * HR_TILE + a_org;
-        const char* rt_tile = ldsR + 2 * wslot * HR_TILE + b_org;
-        u32x4 ah[RT], al[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            ah[rt] = tr_frag(lt, tx[rt][0], tx[rt][1]);
-            al[rt] = tr_frag(lt + 2 * HR_TILE, tx[rt][0], tx[rt][1]);
-        }
-        if (do_cs) {                                      // row sums of do_hi + do_lo over the rows that exist
-            u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-            if (nvalid_cur < HRB) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int kk = 8 * lg + 2 * d;
-                    ones[d] = (kk < nvalid_cur ? 0x3f80u : 0u) | (kk + 1 < nvalid_cur ? 0x3f800000u : 0u);
-                }
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                csacc[rt] = X::mma(ah[rt], ones, csacc[rt]);
-                csacc[rt] = X::mma(al[rt], ones, csacc[rt]);
-            }
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const char* bt = rt_tile + 512 * (ct >> 1);
-            const u32x4 bh = tr_frag(bt, tx[ct & 1][0], tx[ct & 1][1]);
-            const u32x4 bl = tr_frag(bt + HR_TILE, tx[ct & 1][0], tx[ct & 1][1]);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                acc[rt][ct] = X::mma(ah[rt], bl, acc[rt][ct]);        // small terms first
-                acc[rt][ct] = X::mma(al[rt], bh, acc[rt][ct]);
-                acc[rt][ct] = X::mma(ah[rt], bh, acc[rt][ct]);
-            }
-        }
-    };
 
     if (rbeg < rend) {
         issue_dma(rbeg, 0);
@@ -195,7 +160,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
     for (int64_t base = rbeg; base < rend; base += HRB, cur ^= 1) {
         const bool more = base + HRB < rend;
         const int nvalid_cur = (int)((rend - base) < HRB ? (rend - base) : HRB);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's lhs tiles, x chunks and probabilities landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" : "+v"(plr));
         {
             const float pv = probs_on(base) ? plr : 0.f;
@@ -209,7 +174,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
             issue_dma(base + HRB, cur ^ 1);
             load_probs(base + HRB);
         }
-        const f32x2* plc = pl + prow * (MAXS * M_) + half * SPH * M_;
+        const f32x2* plc = pl + prow * (MAXS * M_);
         f32x2 xv[M_][4];
 #pragma unroll
         for (int m = 0; m < M_; ++m)
@@ -220,18 +185,18 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
         for (int m = 0; m < M_; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[m][i]));
-        if (more) load_x(base + HRB);                     // the chunk registers are free again: next step's chunk flies
+        if (more) load_x(base + HRB);
         const int woff = tr_off(prow, pc);
 #pragma unroll
-        for (int s2 = 0; s2 < SPH; ++s2) {
-            // (a slot the tile does not have carries zero probabilities: straight-line code, no test against nslots)
+        for (int sl = 0; sl < MAXS; ++sl) {
+            if (MAXS > 2 && sl >= nslots) continue;       // (two slots: straight-line code, a missing slot has zero probabilities)
             f32x2 pv[4];
-            const f32x2 p0 = plc[s2 * M_];
+            const f32x2 p0 = plc[sl * M_];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pv[i] = xv[0][i] * p0;
 #pragma unroll
             for (int m = 1; m < M_; ++m) {
-                const f32x2 pm_ = plc[s2 * M_ + m];
+                const f32x2 pm_ = plc[sl * M_ + m];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pv[i] = __builtin_elementwise_fma(xv[m][i], pm_, pv[i]);
             }
@@ -243,13 +208,49 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
                 oh[i] = h_;
                 ol[i] = l_;
             }
-            char* dst = ldsR + 2 * (half * SPH + s2) * HR_TILE + woff;
+            char* dst = ldsR + 2 * sl * HR_TILE + woff;
             *reinterpret_cast<u32x4*>(dst) = oh;
             *reinterpret_cast<u32x4*>(dst + HR_TILE) = ol;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // pooled tiles visible
-        mma_phase(cur, nvalid_cur);
+        {
+            const char* lt = ldsL + 2 * cur * HR_TILE + a_org;
+            const char* rt_tile = ldsR + 2 * wslot * HR_TILE + b_org;
+            u32x4 ah[RT], al[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                ah[rt] = tr_frag(lt, tx[rt][0], tx[rt][1]);
+                al[rt] = tr_frag(lt + HR_TILE, tx[rt][0], tx[rt][1]);
+            }
+            if (do_cs) {
+                u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                if (nvalid_cur < HRB) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int kk = 8 * lg + 2 * d;
+                        ones[d] = (kk < nvalid_cur ? 0x3f80u : 0u) | (kk + 1 < nvalid_cur ? 0x3f800000u : 0u);
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    csacc[rt] = X::mma(ah[rt], ones, csacc[rt]);
+                    csacc[rt] = X::mma(al[rt], ones, csacc[rt]);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const char* bt = rt_tile + 512 * (ct >> 1);
+                const u32x4 bh = tr_frag(bt, tx[ct & 1][0], tx[ct & 1][1]);
+                const u32x4 bl = tr_frag(bt + HR_TILE, tx[ct & 1][0], tx[ct & 1][1]);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][ct] = X::mma(ah[rt], bl, acc[rt][ct]);
+                    acc[rt][ct] = X::mma(al[rt], bh, acc[rt][ct]);
+                    acc[rt][ct] = X::mma(ah[rt], bh, acc[rt][ct]);
+                }
+            }
+        }
     }
 
     float* out = p.out + (int64_t)split * E * E;
@@ -270,12 +271,17 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_hilo_wide_kernel(GemmTnArgs p
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dW_o: 512 threads = 8 waves as 4 (j) x 2 (k), block tile 128 x 128, wave tile 32 x 64; lhs = dy (one tile), rhs = o_hi and
-// o_lo (two tiles), all by LDS-DMA into two stages of 24 KB: three blocks per CU.
-__global__ __launch_bounds__(512, 3) void gemm_tn_hilo_plain_kernel(GemmTnArgs p) {
+// Plain product (dW_o = dy^T o): 512 threads = 8 waves as 2 (j) x 4 (k), block tile 128 x 128, wave tile 64 x 32; every tile by
+// LDS-DMA into a RING of D stages, the copy of step k + D - 1 issued at step k: a 32-row step is ~0.2 us of MFMAs, far less
+// than a trip to HBM, so one step of lead (the two-buffer form) left every step waiting for its tiles (measured: 64 steps of
+// ~1.3 us).  HILO: rhs = o_hi and o_lo (two tiles per stage, two MFMAs per fragment pair); its lhs dy is an exact input.
+template <bool HILO, int D>
+__global__ __launch_bounds__(512, 4) void gemm_tn_ring_kernel(GemmTnArgs p) {
     using X = Tr<BF16>;
-    constexpr int RT = 2, CT = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 stages][lhs | rhs hi | rhs lo]
+    constexpr int RT = 4, CT = 2, WK = 4;
+    constexpr int NI = HILO ? 3 : 2;                                  // DMA instructions per thread and step
+    constexpr int STAGE = NI * HR_TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [D stages][lhs | rhs hi | rhs lo]
 
     const int E = p.E;
     const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4, w = wave_id();
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(512, 3) void gemm_tn_hilo_plain_kernel(GemmTnArgs p
     const int64_t rbeg = (int64_t)split * p.rows_per_split;
     const int64_t rend = (rbeg + p.rows_per_split) < p.B ? (rbeg + p.rows_per_split) : p.B;
 
-    const int j0w = 32 * (w >> 1), k0w = 64 * (w & 1);
+    const int j0w = 16 * RT * (w / WK), k0w = 16 * CT * (w % WK);
     const bool do_cs = p.colsum != nullptr && kt_idx == 0 && k0w == 0;
     const int q = r16 >> 2, pp = r16 & 3;
     int tx[2][2];
@@ -297,8 +303,8 @@ __global__ __launch_bounds__(512, 3) void gemm_tn_hilo_plain_kernel(GemmTnArgs p
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
             tx[b1][hh] = 2048 * lg + 64 * q + 8 * (pp & 1) + 256 * hh + 16 * ((2 * b1 + (pp >> 1)) ^ (2 * (lg & 1) + hh));
-    const int a_org = 512 * (w >> 1);
-    const int b_org = 1024 * (w & 1);
+    const int a_org = 512 * (j0w >> 5);                   // 16-column block j0w / 16 + rt: pair (j0w >> 5) + (rt >> 1), parity rt & 1
+    const int b_org = 512 * (k0w >> 5);
 
     f32x4 acc[RT][CT];
 #pragma unroll
@@ -314,35 +320,39 @@ __global__ __launch_bounds__(512, 3) void gemm_tn_hilo_plain_kernel(GemmTnArgs p
     const char* rhs_lo = reinterpret_cast<const char*>(p.rhs_lo);
     const unsigned int ld = (unsigned)E * 2u;
 
-    auto issue_dma = [&](int64_t base, int buf) {
+    auto issue_dma = [&](int64_t base, int stage) {
         const int nvalid = (int)((rend - base) < HRB ? (rend - base) : HRB);
-        char* st = smem + 3 * buf * HR_TILE;
+        char* st = smem + stage * STAGE;
         dma_hr_images(lhs + base * (int64_t)ld + (int64_t)j0 * 2, ld, nvalid, st);
         dma_hr_images(rhs_hi + base * (int64_t)ld + (int64_t)k0 * 2, ld, nvalid, st + HR_TILE);
-        dma_hr_images(rhs_lo + base * (int64_t)ld + (int64_t)k0 * 2, ld, nvalid, st + 2 * HR_TILE);
+        if (HILO) dma_hr_images(rhs_lo + base * (int64_t)ld + (int64_t)k0 * 2, ld, nvalid, st + 2 * HR_TILE);
     };
 
-    if (rbeg < rend) issue_dma(rbeg, 0);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (rbeg + (int64_t)d * HRB < rend) issue_dma(rbeg + (int64_t)d * HRB, d);
     int cur = 0;
-    for (int64_t base = rbeg; base < rend; base += HRB, cur ^= 1) {
-        const bool more = base + HRB < rend;
+    for (int64_t base = rbeg; base < rend; base += HRB, cur = cur == D - 1 ? 0 : cur + 1) {
         const int nvalid_cur = (int)((rend - base) < HRB ? (rend - base) : HRB);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this step's tiles landed (issued one step ago)
-        __builtin_amdgcn_s_barrier();                          // ... for every wave; MFMAs of the previous step done
-        char* st = smem + 3 * cur * HR_TILE;
+        // this step's tiles landed: behind them only the copies of the next D - 2 steps may still fly (in-order completion);
+        // near the end fewer are in flight than that count assumes, so the tail waits for everything
+        if (base + (int64_t)(D - 2) * HRB < rend) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 2) * NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // ... for every wave; the stage read at the previous step is free
+        char* st = smem + cur * STAGE;
         if (nvalid_cur < HRB) {                                // ragged last step: zero the rhs rows that do not exist
             for (int c = threadIdx.x; c < (HRB - nvalid_cur) * 16; c += 512) {
                 const int off = tr_off(nvalid_cur + (c >> 4), c & 15);
                 *reinterpret_cast<u32x4*>(st + HR_TILE + off) = u32x4{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4*>(st + 2 * HR_TILE + off) = u32x4{0u, 0u, 0u, 0u};
+                if (HILO) *reinterpret_cast<u32x4*>(st + 2 * HR_TILE + off) = u32x4{0u, 0u, 0u, 0u};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if (more) issue_dma(base + HRB, cur ^ 1);
+        if (base + (int64_t)(D - 1) * HRB < rend) issue_dma(base + (int64_t)(D - 1) * HRB, cur == 0 ? D - 1 : cur - 1);
         u32x4 a[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[rt] = tr_frag(st + a_org, tx[rt][0], tx[rt][1]);
+        for (int rt = 0; rt < RT; ++rt) a[rt] = tr_frag(st + a_org + 512 * (rt >> 1), tx[rt & 1][0], tx[rt & 1][1]);
         if (do_cs) {
             u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
             if (nvalid_cur < HRB) {
@@ -359,12 +369,13 @@ __global__ __launch_bounds__(512, 3) void gemm_tn_hilo_plain_kernel(GemmTnArgs p
         for (int ct = 0; ct < CT; ++ct) {
             const char* bt = st + HR_TILE + b_org + 512 * (ct >> 1);
             const u32x4 bh = tr_frag(bt, tx[ct & 1][0], tx[ct & 1][1]);
-            const u32x4 bl = tr_frag(bt + HR_TILE, tx[ct & 1][0], tx[ct & 1][1]);
+            if (HILO) {
+                const u32x4 bl = tr_frag(bt + HR_TILE, tx[ct & 1][0], tx[ct & 1][1]);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                acc[rt][ct] = X::mma(a[rt], bl, acc[rt][ct]);
-                acc[rt][ct] = X::mma(a[rt], bh, acc[rt][ct]);
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = X::mma(a[rt], bl, acc[rt][ct]);
             }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = X::mma(a[rt], bh, acc[rt][ct]);
         }
     }
 
@@ -386,18 +397,18 @@ __global__ __launch_bounds__(512, 3) void gemm_tn_hilo_plain_kernel(GemmTnArgs p
 }
 
 template <int M_, int MAXS>
-void launch_hilo_wide(const GemmTnArgs& a, hipStream_t s) {
-    const size_t smem = (size_t)(8 + 2 * MAXS) * HR_TILE + (size_t)HRB * MAXS * M_ * 2 * sizeof(float);
-    dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)((a.E / 128) * (a.E / 256)))), block(1024);
-    auto kern = gemm_tn_hilo_wide_kernel<M_, MAXS>;
+void launch_hilo_pooled(const GemmTnArgs& a, hipStream_t s) {
+    const size_t smem = (size_t)(4 + 2 * MAXS) * HR_TILE + (size_t)HRB * MAXS * M_ * 2 * sizeof(float);
+    dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)((a.E / 128) * (a.E / 128)))), block(512);
+    auto kern = gemm_tn_hilo_pooled_kernel<M_, MAXS>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     kern<<<grid, block, smem, s>>>(a);
 }
 
-int hilo_slots_256(int E, int hd) {               // head slots of the widest aligned 256-row window, rounded up to even
+int hilo_slots_128(int E, int hd) {               // head slots of the widest aligned 128-row window: 1 or 2 -> 2, 3 or 4 -> 4
     int mx = 1;
-    for (int j0 = 0; j0 < E; j0 += 256) {
-        const int n = (j0 + 255) / hd - j0 / hd + 1;
+    for (int j0 = 0; j0 < E; j0 += 128) {
+        const int n = (j0 + 127) / hd - j0 / hd + 1;
         if (n > mx) mx = n;
     }
     return mx <= 2 ? 2 : (mx <= 4 ? 4 : 0);
@@ -405,25 +416,37 @@ int hilo_slots_256(int E, int hd) {               // head slots of the widest al
 
 }  // namespace
 
-// shapes of the one-launch hi + lo products: E a multiple of 256 (256-row j tiles, 128-column k tiles), at most 4 head slots
-// per j tile, M <= 3 (the 128-VGPR budget of the 1024-thread block), rows_per_split a multiple of 32
+// shapes of the one-launch hi + lo products: E a multiple of 128 (128 x 128 block tiles), at most 4 head slots per 128 rows,
+// M <= 3 (the 128-VGPR budget of the pooled kernel), rows_per_split a multiple of 32
 bool gemm_tn_hilo_supported(const GemmTnArgs& a) {
-    if (a.E % 256 != 0 || a.M < 1 || a.M > 3 || (a.Ej > 0 && a.Ej != a.E) || a.rows_per_split % HRB != 0) return false;
-    return !a.pooled || hilo_slots_256(a.E, a.hd) != 0;
+    if (a.E % 128 != 0 || a.M < 1 || a.M > 3 || (a.Ej > 0 && a.Ej != a.E) || a.rows_per_split % HRB != 0) return false;
+    return !a.pooled || hilo_slots_128(a.E, a.hd) != 0;
 }
 
 void launch_gemm_tn_hilo(const GemmTnArgs& a, hipStream_t s) {
     if (!a.pooled) {
-        const size_t smem = (size_t)6 * HR_TILE;
+        // the plain product with both rhs tiles of a step (o_hi, o_lo): a ring of three 24 KB stages, two blocks per CU (75 us at
+        // the headline shape; two stages: 85).  Without rhs_lo the same kernel runs the default product -- kept for shapes
+        // tests exercise; the default path's 64-row two-buffer kernel is faster there (46 against 53 us)
         dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)((a.E / 128) * (a.E / 128)))), block(512);
-        gemm_tn_hilo_plain_kernel<<<grid, block, smem, s>>>(a);
+        if (a.rhs_lo) {
+            const size_t smem = (size_t)3 * 3 * HR_TILE;
+            auto kern = gemm_tn_ring_kernel<true, 3>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            kern<<<grid, block, smem, s>>>(a);
+        } else {
+            const size_t smem = (size_t)4 * 2 * HR_TILE;
+            auto kern = gemm_tn_ring_kernel<false, 4>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            kern<<<grid, block, smem, s>>>(a);
+        }
         return;
     }
-    const bool two = hilo_slots_256(a.E, a.hd) == 2;
+    const bool two128 = hilo_slots_128(a.E, a.hd) == 2;
     switch (a.M) {
-        case 1: if (two) launch_hilo_wide<1, 2>(a, s); else launch_hilo_wide<1, 4>(a, s); return;
-        case 2: if (two) launch_hilo_wide<2, 2>(a, s); else launch_hilo_wide<2, 4>(a, s); return;
-        default: if (two) launch_hilo_wide<3, 2>(a, s); else launch_hilo_wide<3, 4>(a, s); return;
+        case 1: if (two128) launch_hilo_pooled<1, 2>(a, s); else launch_hilo_pooled<1, 4>(a, s); return;
+        case 2: if (two128) launch_hilo_pooled<2, 2>(a, s); else launch_hilo_pooled<2, 4>(a, s); return;
+        default: if (two128) launch_hilo_pooled<3, 2>(a, s); else launch_hilo_pooled<3, 4>(a, s); return;
     }
 }
 

@@ -171,6 +171,7 @@ def attach(pool, group=None, average: bool = True, keep_f32: bool = True, defer_
     ref = weakref.ref(pool)
     for p in pool.parameters():
         _attached[id(p)] = ref
+        st.add_scaled(p)
     return st
 
 
@@ -255,17 +256,26 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
     _, world = world_info(group)
     if (world == 1 and not (rehearse and dist.is_initialized())) or not params:
         return
+    # parameters whose gradients an attached pool's backward already multiplied by 1 / world (the module's own and the leaf
+    # fusion queries it has seen: layer.DpState.scaled) go through their own collective, without the divide
+    states = [st for st in _all_states() if st.grad_scale != 1.0]
+    pre = [p for p in params if any(st.is_scaled(p) for st in states)]
+    if pre and len(pre) < len(params):
+        taken = {id(p) for p in pre}
+        all_reduce_grads(pre, group, average, fp32, rehearse)
+        all_reduce_grads([p for p in params if id(p) not in taken], group, average, fp32, rehearse)
+        return
+    prescaled = bool(pre)
     flat = flat_grad_alias(params)
     reduced = any(p.grad.dtype in (torch.bfloat16, torch.float16) for p in params)
     if fp32 is None:
         fp32 = reduced
-    # what the attached module's backward left about this very run: its float32 sums (bf16 parameters) and whether the
-    # gradients already carry the factor 1 / world (attach: grad_scale)
-    wide, prescaled = None, False
-    for st in _states_of(params):
-        w_, pre_ = st.take(flat)
-        if w_ is not None or pre_:
-            wide, prescaled = w_, pre_
+    # the float32 sums the backward kept behind this very run (bf16 parameters, dp.attach(keep_f32=True))
+    wide = None
+    for st in _all_states():
+        w_ = st.take(flat)
+        if w_ is not None:
+            wide = w_
     if prescaled and not average:
         raise RuntimeError("all_reduce_grads(average=False) on gradients an attached pool already divided by world")
     divide = average and not prescaled
@@ -332,6 +342,7 @@ class GradOverlap:
         self.stream = None
         self.pending = []                                   # (flat, work) of every collective issued since the last finish
         self._hooked = []                                   # DpStates this region installed itself on
+        self._fired = []                                    # ... and those whose backward has called the hook since the last finish
 
     def __enter__(self):
         _, world = world_info(self.group)
@@ -363,10 +374,12 @@ class GradOverlap:
     def __call__(self, flat: torch.Tensor, event, flat32: Optional[torch.Tensor] = None, state=None) -> None:
         # reduced-precision gradients whose float32 sums the backward kept: the collective runs on THOSE and finish() rounds the
         # mean into `flat` (the allocation autograd holds, left uninitialised by the backward) once
-        prescaled = False
-        if state is not None and state.last is not None:
-            prescaled = bool(state.last[3])
-            state.last = None                                # consumed here, not by all_reduce_grads
+        prescaled = state is not None and state.grad_scale != 1.0
+        if state is not None:
+            if state.runs:
+                state.runs.pop()                             # this call's record: consumed here, not by all_reduce_grads
+            if not any(st is state for st in self._fired):
+                self._fired.append(state)
         low = None
         if flat32 is not None:
             low, flat = flat, flat32
@@ -404,20 +417,23 @@ class GradOverlap:
         _, world = world_info(self.group)
         pending, self.pending = self.pending, []
         if world == 1 or not params:
+            self._fired = []
             return
         if not pending:                                     # the hook never fired (no fused backward ran): plain path
             all_reduce_grads(params, self.group, self.average)
             return
-        spans = []
+        fired, self._fired = self._fired, []
         for flat, work, wide in pending:
             if work is not None:
                 work.wait()
-            spans.append((flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
         torch.cuda.current_stream().wait_stream(self.stream)
         for flat, _, wide in pending:
             if wide is not None:
                 flat.copy_(wide)                             # ONE rounding of the float32 mean, in place
-        rest = [p for p in params if not any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]
+        # covered = the gradients of the modules whose backward called the hook (their parameters and the leaf queries they saw),
+        # WHEREVER autograd has put them since: two pool applications in one backward are summed into fresh allocations, and a
+        # sum of reduced gradients must not be reduced again
+        rest = [p for p in params if not any(st.is_scaled(p) for st in fired)]
         if rest:
             all_reduce_grads(rest, self.group, self.average)
 

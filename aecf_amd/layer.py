@@ -137,29 +137,52 @@ class DpState:
     """Data-parallel state of ONE pool module (``aecf_amd.dp.attach`` makes it; nothing here is process-global).
 
     ``grad_scale``: factor the backward folds into the five parameter gradients as it stores them (1 / world: the gradient
-    average is then ONE sum all-reduce, no divide launch).  ``keep_f32``: bf16 parameters -- the backward writes its float32
-    batch sums, the collective averages THOSE and the bf16 gradient is rounded once from the mean.  ``defer_rounding``: with
-    ``keep_f32`` the bf16 tensors autograd receives stay UNINITIALISED until ``dp.all_reduce_grads`` / ``GradOverlap.finish``
-    writes the rounded mean into them (no cast launch in the backward; reading ``p.grad`` before the collective is an error).
-    ``hook``: a ``dp.GradOverlap`` while one is active.  ``last``: (flat, flat32, version, prescaled) of the last backward."""
-    __slots__ = ("world", "grad_scale", "keep_f32", "defer_rounding", "hook", "last")
+    average is then ONE sum all-reduce, no divide launch).  ``scaled``: the leaf tensors whose gradients carry that factor -- the
+    module's parameters and every leaf fusion query its forward has seen (weak references) -- which is how
+    ``dp.all_reduce_grads`` knows not to divide them again, whatever autograd did with the tensors in between (two pool
+    applications in one backward are summed into fresh allocations).
+    ``keep_f32``: bf16 parameters -- the backward writes its float32 batch sums, the collective averages THOSE and the bf16
+    gradient is rounded once from the mean.  ``defer_rounding``: with ``keep_f32`` the bf16 tensors autograd receives stay
+    UNINITIALISED until ``dp.all_reduce_grads`` / ``GradOverlap.finish`` writes the rounded mean into them (no cast launch;
+    reading ``p.grad`` before the collective is an error).  ``hook``: a ``dp.GradOverlap`` while one is active.
+    ``runs``: (flat, flat32, version) of the fused backward calls since the last collective -- where the float32 sums behind a
+    gradient run are found.  The tensors are held (a few MB each, at most 8), so a pointer compared against them cannot have
+    been freed and reused."""
+    __slots__ = ("world", "grad_scale", "keep_f32", "defer_rounding", "hook", "runs", "scaled")
 
     def __init__(self, world: int = 1, grad_scale: float = 1.0, keep_f32: bool = True, defer_rounding: bool = False):
         self.world, self.grad_scale, self.keep_f32, self.defer_rounding = int(world), float(grad_scale), bool(keep_f32), bool(defer_rounding)
         self.hook = None
-        self.last = None
+        self.runs = []
+        self.scaled = {}                           # id(tensor) -> weak reference (identity, never tensor equality)
+
+    def add_scaled(self, t: torch.Tensor) -> None:
+        import weakref
+        if len(self.scaled) > 64:
+            self.scaled = {k: r for k, r in self.scaled.items() if r() is not None}
+        self.scaled[id(t)] = weakref.ref(t)
+
+    def is_scaled(self, t: torch.Tensor) -> bool:
+        r = self.scaled.get(id(t))
+        return r is not None and r() is t
+
+    def record(self, flat, flat32) -> None:
+        if len(self.runs) >= 8:
+            del self.runs[1:-1]
+        self.runs.append((flat, flat32, flat._version))
 
     def take(self, flat: Optional[torch.Tensor]):
-        """(float32 sums or None, prescaled) behind the gradient run ``flat`` (as dp.flat_grad_alias returns it) if the last
-        fused backward of this module wrote that run and nothing has written to it since; consumed by the call."""
-        hit, self.last = self.last, None
-        if hit is None or flat is None:
-            return None, False
-        mine, wide, version, prescaled = hit
-        if (mine._version != version or mine.data_ptr() != flat.data_ptr() or mine.numel() != flat.numel()
-                or mine.dtype != flat.dtype):
-            return None, False
-        return wide, prescaled
+        """The float32 sums behind the gradient run ``flat`` (as dp.flat_grad_alias returns it), if ``flat`` IS a run one of this
+        module's backward calls wrote since the last collective and nothing has written to it since (an accumulation moves its
+        version counter); else None.  Consumes the records."""
+        runs, self.runs = self.runs, []
+        if flat is None:
+            return None
+        for f, w, version in runs:
+            if (w is not None and f._version == version and f.data_ptr() == flat.data_ptr() and f.numel() == flat.numel()
+                    and f.dtype == flat.dtype):
+                return w
+        return None
 
 
 class PoolOptions:
@@ -310,6 +333,9 @@ class _PoolFunction(torch.autograd.Function):
         ctx.save_for_backward(xc, qc, w_in_c, b_in_c, w_out_c, probs, saved_o, attn_w, saved_v, saved_prep, saved_o_lo)
         ctx.desc = desc
         ctx.opts = opts
+        ctx.q_leaf = bool(q.is_leaf)
+        if opts.dp is not None and q.is_leaf and q.requires_grad:
+            opts.dp.add_scaled(q)                  # its gradient will carry grad_scale (dp.all_reduce_grads asks)
         ctx.bwd_ws_bytes = hilo_ws if saved_o_lo is not None else bwd_ws_bytes
         ctx.q_shape = q.shape
         ctx.param_dtypes = (q.dtype, w_in.dtype, None if b_in is None else b_in.dtype, w_out.dtype,
@@ -377,14 +403,24 @@ class _PoolFunction(torch.autograd.Function):
             # on this stream would race it; DpState.defer_rounding: the caller promised to call all_reduce_grads): then the
             # tensors stay uninitialised and the backward has no cast launch at all
             flat32 = flat
-            flat = torch.empty_like(flat32, dtype=gdt) if (hook is not None or dp_.defer_rounding) else flat32.to(gdt)
+            defer = hook is not None or dp_.defer_rounding
+            if defer and hook is None and dp_.runs:
+                # an earlier run of this step is still unreduced and autograd is about to ADD this call's gradients to it (two
+                # pool applications, micro-batches): both get their real values now
+                for f_, w_, v_ in dp_.runs:
+                    if w_ is not None and f_._version == v_:
+                        f_.copy_(w_)
+                defer = False
+            flat = torch.empty_like(flat32, dtype=gdt) if defer else flat32.to(gdt)
             dquery, dw_in, db_in, dw_out, db_out = flat.split([E, 3 * E * E, 3 * E, E * E, E])
             dw_in, dw_out = dw_in.view(3 * E, E), dw_out.view(E, E)
         if dp_ is not None:
-            dp_.last = (flat, flat32, flat._version, gscale != 1.0)     # one entry per module, replaced by every backward
+            dp_.record(flat, flat32)
         if hook is not None:
             hook(flat, early, flat32, dp_)         # [dquery | dw_in | db_in | dw_out | db_out]: final once `early` has fired
         needs = ctx.needs_input_grad
+        if gscale != 1.0 and not ctx.q_leaf and needs[1]:
+            dquery = dquery * (1.0 / gscale)       # a COMPUTED query: its gradient flows on into whoever made it, unscaled like dx
         return (dx if needs[0] else None,
                 dquery.to(qd).reshape(ctx.q_shape) if needs[1] else None,
                 dw_in.to(wid) if needs[2] else None,

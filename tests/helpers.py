@@ -70,7 +70,17 @@ def record_errors(name, **kw):
         f.write(json.dumps(dict(test=name, **{k: float(v) for k, v in kw.items()})) + "\n")
 
 
-from aecf_amd._tolerances import BF16_BOUNDS, BF16_F32GRAD_BOUNDS  # noqa: E402,F401  (one table: the package's)
+from aecf_amd._tolerances import BF16_BOUNDS, BF16_F32GRAD_BOUNDS, BF16_F32GRAD_HILO_BOUNDS  # noqa: E402,F401  (one table: the package's)
+
+
+def f32grad_bounds(B, M, E, H):
+    """Bounds of float32-stored parameter gradients of the bf16 kernels for this shape: the tight table where the library
+    builds the hi + lo weight-gradient products (they are then on by themselves), the bf16-operand table elsewhere."""
+    import ctypes
+    from aecf_amd import _lib
+    desc = _lib.PoolDesc(B, M, E, H, _lib.AECF_BF16, 1, 1, 0.15, 0.7, 1e-8)
+    hilo = _lib.load().aecf_pool_hilo_bwd_workspace_bytes(ctypes.byref(desc)) > 0
+    return BF16_F32GRAD_HILO_BOUNDS if hilo else BF16_F32GRAD_BOUNDS
 
 
 def assert_bf16_bounds(errs, bounds, what, scale=1.0):

@@ -287,14 +287,21 @@ def _attached_worker(rank, world, port, q):
         wide = sums * st.grad_scale                                  # ... as the backward stores them (aecf_pool_bwd_args.grad_scale)
         flat = torch.full((4096,), float("nan"), dtype=torch.bfloat16)     # deferred rounding: autograd's tensors are not written
         pool.w.grad, pool.b.grad = flat[:3840].view(60, 64), flat[3840:]
-        st.last = (flat, wide, flat._version, True)
+        st.record(flat, wide)
         ptr = pool.w.grad.data_ptr()
         dp.all_reduce_grads([pool.w, pool.b])
-        consumed = st.last is None
-        # a second call finds nothing left behind: the bf16 values themselves travel (as float32), divided by world
-        again = flat.float().clone()
+        consumed = not st.runs
+        first = flat.float().clone()
+        # gradients that autograd summed into fresh allocations (two pool applications in one backward): no float32 sums on
+        # record, but still this module's parameters -- still no divide
+        g2 = torch.Generator().manual_seed(200 + rank)
+        va = (torch.randn(3840, generator=g2) * st.grad_scale).to(torch.bfloat16)
+        vb = (torch.randn(256, generator=g2) * st.grad_scale).to(torch.bfloat16)
+        pool.w.grad, pool.b.grad = va.clone().view(60, 64), vb.clone()
         dp.all_reduce_grads([pool.w, pool.b])
-        q.put((rank, st.grad_scale, sums.numpy(), again.numpy(), flat.float().numpy(), pool.w.grad.data_ptr() == ptr, consumed))
+        second = torch.cat([pool.w.grad.reshape(-1).float(), pool.b.grad.float()])
+        q.put((rank, st.grad_scale, sums.numpy(), first.numpy(), second.numpy(), torch.cat([va, vb]).float().numpy(),
+               pool.w.grad.data_ptr() != ptr, consumed))
         dp.detach(pool)
         assert pool.options.dp is None and not dp._states_of([pool.w])
     finally:
@@ -318,8 +325,8 @@ def test_attached_module_gradients_are_prescaled_and_rounded_once():
         assert p.exitcode == 0
     mean = (torch.from_numpy(res[0][2]) * 0.5 + torch.from_numpy(res[1][2]) * 0.5)
     want = mean.to(torch.bfloat16).float()
-    for rank, scale, _, first, second, in_place, consumed in res:
-        assert scale == 0.5 and in_place and consumed
+    want2 = (torch.from_numpy(res[0][5]) + torch.from_numpy(res[1][5])).to(torch.bfloat16).float()    # a plain SUM of pre-scaled values
+    for rank, scale, _, first, second, _, fresh, consumed in res:
+        assert scale == 0.5 and fresh and consumed
         assert torch.equal(torch.from_numpy(first), want), rank
-        # the second, plain call averaged two identical tensors again: unchanged up to one more rounding of the same value
-        assert torch.equal(torch.from_numpy(second), want), rank
+        assert torch.equal(torch.from_numpy(second), want2), rank

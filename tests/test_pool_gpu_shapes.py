@@ -4,7 +4,7 @@ with and without key_padding_mask / gradient on the attention weights.  Checked 
 import pytest
 import torch
 
-from tests.helpers import BF16_F32GRAD_BOUNDS, assert_bf16_bounds, record_errors, rel_err
+from tests.helpers import BF16_F32GRAD_BOUNDS, assert_bf16_bounds, f32grad_bounds, record_errors, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -107,7 +107,7 @@ def test_shapes_bf16(shape, kpm):
     errs, agree = _case(B, M, E, H, torch.bfloat16, kpm, seed=B + M + E + H + 1)
     # per tensor (tests/helpers.py): dquery = W_q^T (scale W_k u), u = ds^T x is a cancellation of bf16-rounded terms (ds
     # sums to zero over the modalities) -- the loosest of the outputs (4.4e-3 measured)
-    assert_bf16_bounds(errs, BF16_F32GRAD_BOUNDS, shape)
+    assert_bf16_bounds(errs, f32grad_bounds(B, M, E, H), shape)
     assert agree > 0.99
 
 
