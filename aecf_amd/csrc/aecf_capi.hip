@@ -72,7 +72,9 @@ BwdWs bwd_layout(const aecf_pool_desc* d, bool hilo = false) {
     const size_t E = d->embed_dim, es = esize(d->dtype);
     const size_t B = (size_t)d->batch;
     const int tiles = (int)(((E + 127) / 128) * ((E + 127) / 128));
-    int S = (512 + tiles - 1) / tiles;                  // ~2 workgroups per CU; slab bytes stay ~32 MB per matrix
+    int S = 512 / tiles;                                // one round of blocks: 2 per CU of the 128-row kernels (512 slots), 1 per
+                                                        // CU of the 256-row pooled kernel (half the tiles, 256 slots); not more --
+                                                        // at d = 768 ceil() made it 15 x 36 = 540 blocks, a second round for 28
     const int64_t max_s = (int64_t)((B + 255) / 256);   // but at least 256 batch rows per split
     if (S > max_s) S = (int)max_s;
     if (S < 1) S = 1;

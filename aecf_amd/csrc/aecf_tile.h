@@ -20,19 +20,23 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * TILE_ROW_BYTES + ((chunk ^ (((row >> 1) ^ (row >> 4)) & 7)) << 4);
 }
 
-// XCD-aware block -> (row panel, column tile) map for [rows x cols] tilings whose column tiles share the row
-// panel's operand: blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2), so the `ncol`
-// column tiles of one row panel get ids b, b+8, b+16, ... -> same XCD, adjacent in time: the panel is fetched from
-// HBM once and re-read from that XCD's L2.  Launch with xcd_grid(npanel, ncol) blocks; returns false for padding ids.
+// XCD-aware block -> (row panel, column tile) map for [rows x cols] tilings whose column tiles share the row panel's operand.
+// Blocks are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2 and its 32 CUs), so XCD x is given the CONTIGUOUS
+// run [x per, (x + 1) per) of the (panel, column) pairs, per = ceil(npanel ncol / 8): the column tiles of a panel sit on one XCD,
+// adjacent in time -- the panel is fetched from HBM once and re-read from that XCD's L2 -- and every XCD gets the same number
+// of blocks.  (Until round 5 whole panels were dealt to the XCDs, panel p to XCD p % 8: with 42 panels of 6 column groups --
+// d = 768 -- two XCDs got 36 one-per-CU blocks for their 32 CUs and the launch took two rounds there.)  Launch with
+// xcd_grid(npanel, ncol) blocks; returns false for padding ids.
 __host__ __device__ __forceinline__ unsigned int xcd_grid(unsigned int npanel, unsigned int ncol) {
-    return ((npanel + 7u) / 8u) * 8u * ncol;
+    return ((npanel * ncol + 7u) / 8u) * 8u;
 }
 __device__ __forceinline__ bool xcd_tile(unsigned int id, unsigned int npanel, unsigned int ncol, unsigned int& panel,
                                          unsigned int& col) {
-    const unsigned int xcd = id & 7u, slot = id >> 3;
-    panel = (slot / ncol) * 8u + xcd;
-    col = slot % ncol;
-    return panel < npanel;
+    const unsigned int total = npanel * ncol, per = (total + 7u) / 8u;
+    const unsigned int q = (id & 7u) * per + (id >> 3);
+    panel = q / ncol;
+    col = q - panel * ncol;
+    return (id >> 3) < per && q < total;
 }
 
 template <typename T> struct TileK;   // elements of K per 128-byte LDS row
