@@ -518,6 +518,8 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
     t1.colsum = (float*)(ws + L.cs_o); t1.u = nullptr; t1.B = B; t1.M = 1; t1.E = E; t1.H = H; t1.hd = hd;
     t1.Ej = 0; t1.splits = L.splits; t1.rows_per_split = L.rows_per_split; t1.pooled = 0;
     t1.u_splits = 0; t1.u_rows_per_split = 0;
+    // (launched here, between dout and the score gradient; moving it behind dW_v so that `do` is consumed while it may still
+    //  sit in the 256 MB memory-side cache measured 0.5 % SLOWER, 4 of 4 same-box pairs: profiles/r05_c2_experiments.txt)
     if (hilo) {                                       // dy^T (o_hi + o_lo): both rhs tiles of a step in one launch
         t1.rhs_lo = a->saved_o_lo;
         launch_gemm_tn_hilo(t1, s);
