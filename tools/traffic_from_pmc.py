@@ -8,7 +8,7 @@ STAGE = [  # (regex on the kernel name, stage)
     (r"gemm_ws_kernel<\d+, [12],", "fwd.vproj"), (r"gate_stats_kernel", "fwd.vproj"), (r"vproj_modal_kernel", "fwd.vproj"),
     (r"vproj_slab_kernel", "fwd.vproj"),
     (r"gemm_ws_kernel<\d+, 0,", "plain_nt"), (r"gemm_nt_kernel", "plain_nt"),
-    (r"gemm_tn_tr_kernel<1, false", "bwd.dw_out"),
+    (r"gemm_tn_tr_kernel<1, false", "bwd.dw_out"), (r"gemm_tn_ring_kernel", "bwd.dw_out"), (r"gemm_tn_hilo_pooled_kernel", "bwd.dw_v"),
     (r"dscore_v_kernel", "bwd.dscore"), (r"dsu_ws_kernel|dsu_slab_kernel", "bwd.dscore"), (r"row_fwd_kernel", "fwd.vproj"),
     (r"dx_ws2?_kernel", "bwd.dx"), (r"bwd_g_kernel", "bwd.dx"),
     (r"gemm_tn_tr_kernel<\d+, true", "bwd.dw_v"), (r"gemm_tn_tr_wide_kernel", "bwd.dw_v"), (r"gemm_tn_u_kernel|u_stream_kernel", "bwd.u"), (r"gemm_tn_kernel", "bwd.dw_v"),
