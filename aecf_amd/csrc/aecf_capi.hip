@@ -638,7 +638,6 @@ int pool_backward_on(const aecf_pool_desc* d, const aecf_pool_bwd_args* a, hipSt
 //   dx_reserve=N        CUs the dx kernel leaves free when it runs beside a collective (default 16, 0..128)
 struct EnvSwitches {
     bool no_ws = false, no_gate_fusion = false, no_wide_tn = false, no_slab = false, fused_fwd = false;
-    int dsu_var = 2;
     int dx_reserve = 16;
 };
 const EnvSwitches& env_switches() {
@@ -658,7 +657,6 @@ const EnvSwitches& env_switches() {
             else if (tok == "no_wide_tn") v.no_wide_tn = true;
             else if (tok == "no_slab") v.no_slab = true;
             else if (tok == "fused_fwd") v.fused_fwd = true;
-            else if (tok.rfind("dsu_var=", 0) == 0) v.dsu_var = atoi(tok.c_str() + 8);
             else if (tok.rfind("dx_reserve=", 0) == 0) {
                 const int n = atoi(tok.c_str() + 11);
                 if (n >= 0 && n <= 128) v.dx_reserve = n;
@@ -679,7 +677,6 @@ namespace aecf {
 bool env_no_ws() { return env_switches().no_ws; }
 bool env_no_wide_tn() { return env_switches().no_wide_tn; }
 bool env_no_slab() { return env_switches().no_slab; }
-int env_dsu_var() { return env_switches().dsu_var; }
 }  // namespace aecf
 
 extern "C" {

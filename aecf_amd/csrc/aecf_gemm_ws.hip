@@ -1006,310 +1006,9 @@ __global__ __launch_bounds__(512, 2) void dsu_ws_kernel(BwdGArgs p, float* __res
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// dsu_ws_kernel restructured around WAVE-PRIVATE x slabs (round 4; the hot shape: E = 512, 64-wide heads, M <= 3).
-// In dsu_ws_kernel every use of the x tile by wave w touches only ITS 64 columns k -- the dot multiplies the wave's P columns,
-// the u product forms the wave's rows of u^T -- yet the tile is a block-wide object: three barriers per 16-sample step, all
-// eight waves in the same phase at the same time, and four of them idle while the other four run the softmax backward.
-// Here (the layout idea of vproj_slab_kernel):
-//   * wave w copies bytes [128 w, 128 w + 128) of every (sample, modality) row into its own slab (rows modality-major,
-//     row = 16 m + sample, 16-byte chunk c at c ^ (sample & 7): conflict-free for the dot's ds_read_b128 and -- with the u
-//     product's K slots numbered so that a 32-lane half reads 8 samples that differ in sample & 7 -- for its transposed reads);
-//     nobody else reads or writes that slab: its hazards are the wave's own program order plus vmcnt;
-//   * the softmax backward is done by EVERY wave for all the block's heads (lane = (sample, head): the sum over the modalities
-//     is in-lane), from the eight partial dots per value that all waves exchange through LDS; each wave parks the bf16 hi / lo
-//     ds operands of the u product in a private 1 KB array (rows = the block's 4 heads; the other 12 MFMA rows read a zero row);
-//   * what remains shared: the do tile (one DMA piece per wave) and the partial dots (double buffered) -> ONE barrier per
-//     step, in the middle: it publishes the step's partials and the next step's do tile (each wave waits for its own piece
-//     with a counted vmcnt: the do piece is the oldest of the step's copies).
-// Per step and wave: P_h (32 MFMAs) + dot -> partials | barrier | softmax backward (all heads) -> u (16 MFMAs) | vmcnt(0).
-template <int M_>
-__global__ __launch_bounds__(512, 2) void dsu_slab_kernel(BwdGArgs p, float* __restrict__ u_slab, int rows_per_block, int nchunk) {
-    using X = Tr<BF16>;
-    constexpr int KJ = 8, HK = 2, E = 512, JB = 256, NCT = 4, HBL = 4, HG = 2;
-    constexpr int SB = 128;                                        // slab row bytes
-    constexpr int XROWS = 16 * M_;
-    constexpr int SLAB = XROWS * SB;                               // one wave's slab of a tile
-    constexpr int XT = 8 * SLAB;                                   // all eight slabs of a tile
-    constexpr int NDMA = XROWS * SB / 1024;                        // 1 KB pieces per wave and tile
-    constexpr int ROWD = 2 * JB, DT = 16 * ROWD;
-    constexpr int KU = (XROWS + 31) / 32;                          // K-steps of the u product
-    constexpr int PTW = HBL * 16 * 4;                              // floats of one wave's partials: [head][sample][m (padded to 4)]
-    constexpr int PT = 8 * PTW;
-    constexpr int DSROW = 72;                                      // ds operand row: 64 K slots + 8 (rows start 9 x 16 B apart)
-    constexpr int DSW = 2 * HBL * DSROW;                           // shorts of one wave's private operand arrays (hi rows, lo rows)
-    static_assert(M_ >= 1 && M_ <= 3 && SLAB % 1024 == 0, "shape");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xb = smem;                                               // [2][8 waves][16 M rows][128 B]
-    char* zp = smem + 2 * XT;                                      // 256 zero bytes (K padding rows of both operands)
-    char* db = zp + 256;                                           // [3][16][JB] do rows, chunk ^ row
-    float* part = reinterpret_cast<float*>(db + 3 * DT);           // [2][8][HBL][16][4]
-    unsigned short* dsw = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(part) + 2 * PT * 4);   // [8][2][HBL][DSROW]
-
-    const int lane = lane_id(), r16 = lane & 15, lg = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(wave_id());
-    const int H = p.H;
-    unsigned int chunk_u, group_u;
-    if (!xcd_tile(blockIdx.x, (unsigned)nchunk, (unsigned)(E / JB), chunk_u, group_u)) return;
-    const int jbase = (int)group_u * JB, hbase = jbase / (32 * HK);
-    const int ncol0 = 64 * w;
-    const int64_t o_beg = (int64_t)chunk_u * rows_per_block;
-    const int64_t o_end = (o_beg + rows_per_block) < p.B ? (o_beg + rows_per_block) : p.B;
-    if (o_beg >= o_end) return;
-
-    const char* dsrc = reinterpret_cast<const char*>(p.dobuf) + (int64_t)jbase * 2;
-    const char* xsrc = reinterpret_cast<const char*>(p.x);
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"      // m0 is named as a clobber on purpose
-    auto issue_do = [&](int64_t o0, int buf) {
-        const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
-        // this wave's 1 KB piece of the [16][512 B] tile: rows 2 w, 2 w + 1; chunk ^ row on the source side
-        const int row = 2 * w + (lane >> 5), pc = lane & 31;
-        const int rowc = row < ov ? row : ov - 1;
-        const unsigned int voff = (unsigned)rowc * (unsigned)(2 * E) + (unsigned)((pc ^ (row & 15)) << 4);
-        const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(db + buf * DT + w * 1024);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(dsrc + o0 * (int64_t)(2 * E)), "s"(dst)
-                     : "memory", "m0");
-    };
-    // piece i (1 KB: 8 slab rows) of this wave's slab of the tile at o0
-    auto issue_x_piece = [&](int64_t o0, int buf, int i) {
-        const int ov = (int)((o_end - o0) < 16 ? (o_end - o0) : 16);
-        const char* src = xsrc + o0 * M_ * (int64_t)(2 * E) + SB * w;
-        const int rho = 8 * i + (lane >> 3), m = rho >> 4, b = rho & 15;
-        const int bc = b < ov ? b : ov - 1;
-        const unsigned int voff = (unsigned)(bc * M_ + m) * (unsigned)(2 * E) + (unsigned)(((lane & 7) ^ (b & 7)) << 4);
-        const unsigned int dst = (unsigned)(size_t)(lds_void_t*)(xb + buf * XT + w * SLAB + 1024 * i);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst)
-                     : "memory", "m0");
-    };
-    auto issue_x = [&](int64_t o0, int buf) {
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) issue_x_piece(o0, buf, i);
-    };
-#pragma clang diagnostic pop
-    // what no copy ever writes: the zero rows and this wave's operand arrays (their padding slots stay zero)
-    if (threadIdx.x < 64) reinterpret_cast<unsigned int*>(zp)[threadIdx.x] = 0u;
-    unsigned short* dsw_w = dsw + w * DSW;
-    for (int i = lane; i < DSW / 2; i += 64) reinterpret_cast<unsigned int*>(dsw_w)[i] = 0u;
-    issue_do(o_beg, 0);
-    if (o_beg + 16 < o_end) issue_do(o_beg + 16, 1);
-    issue_x(o_beg, 0);
-
-    // ---- resident weights (as dsu_ws_kernel, 16-byte-dot row order): A operand row r16 of tile ct <-> column
-    //      k = ncol0 + 32 (ct >> 1) + 8 (r16 >> 2) + 4 (ct & 1) + (r16 & 3), K = j
-    const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.wvt);
-    u32x4 wreg[KJ][NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const int krow = ncol0 + 32 * (ct >> 1) + 8 * (r16 >> 2) + 4 * (ct & 1) + (r16 & 3);
-        const unsigned short* wr = wsrc + (int64_t)krow * E + jbase + 8 * lg;
-#pragma unroll
-        for (int ks = 0; ks < KJ; ++ks) wreg[ks][ct] = *reinterpret_cast<const u32x4*>(wr + 32 * ks);
-    }
-    int daddr[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) daddr[v] = r16 * ROWD + ((((4 * v) + lg) ^ r16) << 4);
-    // dot: the 16-byte piece (columns ncol0 + 32 c2 + 8 lg .. + 7) of slab row 16 m + r16: chunk (4 c2 + lg) ^ (r16 & 7)
-    const int xaddr0 = w * SLAB + r16 * SB + ((lg ^ (r16 & 7)) << 4);          // c2 = 1: ^ 64
-    // u product, A operand by transposed reads of the slab.  K slot s = 32 ks + 8 lg + 4 hh + q  <->  (modality, sample) through
-    // the domain D = 4 ks + 2 hh + (lg >> 1) = 2 m + (b >> 3), b & 7 = 4 (lg & 1) + q: the 8 rows a 32-lane half of one read
-    // touches are 8 samples of one modality that differ in b & 7 = the swizzle key -> 8 x 32 B tile the 256-byte bank window
-    const int q = r16 >> 2, pp = r16 & 3;
-    int ua[KU][2];
-#pragma unroll
-    for (int ks = 0; ks < KU; ++ks)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int D = 4 * ks + 2 * hh + (lg >> 1);
-            const int m = D >> 1, b = 8 * (D & 1) + 4 * (lg & 1) + q;
-            ua[ks][hh] = D >= 2 * M_ ? -1 : w * SLAB + (16 * m + b) * SB + (((pp >> 1) ^ (b & 7)) << 4) + 8 * (pp & 1);
-        }
-    auto kslot = [&](int b, int m) -> int {
-        const int D = 2 * m + (b >> 3), j = b & 7;
-        return 32 * (D >> 2) + 8 * (2 * (D & 1) + (j >> 2)) + 4 * ((D >> 1) & 1) + (j & 3);
-    };
-    // B operand rows of the u product: row r16 = local head (< HBL: this wave's private arrays; else the zero row)
-    const int bh_off = r16 < HBL ? (int)(reinterpret_cast<char*>(dsw_w) - smem) + (r16 * DSROW + 8 * lg) * 2
-                                 : (int)(zp - smem) + 16 * lg;
-    const int bl_off = r16 < HBL ? bh_off + HBL * DSROW * 2 : bh_off;
-
-    // statistics of this lane's (sample r16, head lg) one step ahead: softmax weights, upstream weight gradient
-    const float invH = 1.0f / (float)H;
-    float pmv[M_], dwb[M_], pmv_n[M_], dwb_n[M_];
-#pragma unroll
-    for (int m = 0; m < M_; ++m) { pmv[m] = dwb[m] = pmv_n[m] = dwb_n[m] = 0.f; }
-    auto load_stats = [&](int64_t o0, float* pv, float* dv) {
-        int64_t b = o0 + r16;
-        b = b < o_end ? b : o_end - 1;
-        const float* pp_ = p.probs + (b * H + hbase + lg) * M_;
-        const float* dw_ = p.d_attn_w ? p.d_attn_w + b * M_ : pp_;
-#pragma unroll
-        for (int m = 0; m < M_; ++m) {
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pv[m]) : "v"(pp_ + m) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(dv[m]) : "v"(dw_ + m) : "memory");
-        }
-    };
-
-    f32x4 uacc[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) uacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KJ; ++ks)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) asm volatile("" : "+v"(wreg[ks][ct]));     // (weights' loads retired here, not in the loop)
-    {   // the first step's statistics by ordinary loads (hipcc counts them; an asm load in a prologue can be copied to
-        // another register before it has landed: profiles/r01_pmc_notes.md)
-        const int64_t b0 = (o_beg + r16) < o_end ? (o_beg + r16) : (o_end - 1);
-#pragma unroll
-        for (int m = 0; m < M_; ++m) {
-            pmv[m] = p.probs[(b0 * H + hbase + lg) * M_ + m];
-            dwb[m] = p.d_attn_w ? p.d_attn_w[b0 * M_ + m] : 0.f;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                  // do tile 0, zero rows visible
-
-    int cur = 0, dcur = 0;
-    for (int64_t o0 = o_beg; o0 < o_end; o0 += 16, cur ^= 1, dcur = dcur == 2 ? 0 : dcur + 1) {
-        const bool more = o0 + 16 < o_end;
-        // copies: the do piece of the step AFTER the next (three do buffers: its last readers passed the previous step's
-        // barrier; it is retired by the NEXT step's end-of-step vmcnt(0) and published by that step's barrier... a whole step and
-        // a half in flight, and the barrier below waits for no copy), this wave's slab and statistics of the next step
-        // (X[cur ^ 1] is this wave's own: its last readers, the u product's MFMAs of the previous step, have been issued)
-        if (o0 + 32 < o_end) issue_do(o0 + 32, dcur == 0 ? 2 : dcur - 1);
-        // (the slab's NDMA = 2 M pieces go out one per (head group, modality) pass of phase 1 below: a copy instruction costs its
-        //  wave 100-200 issue cycles -- seven in a row at the top of the step were ~1000 cycles in front of the first MFMA)
-        if (more) load_stats(o0 + 16, pmv_n, dwb_n);
-        // ---- phase 1: P_h by MFMA, dot with this lane's x values, partial dots to LDS
-        const char* tb = db + dcur * DT;
-        const char* xs = xb + cur * XT;
-        float* pw = part + cur * PT + w * PTW + r16 * 4;
-#pragma unroll
-        for (int h0 = 0; h0 < HBL; h0 += HG) {
-            f32x4 P[HG][NCT];
-#pragma unroll
-            for (int g = 0; g < HG; ++g) {
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) P[g][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kl = 0; kl < HK; ++kl) {
-                    const int ks = (h0 + g) * HK + kl;
-                    const u32x4 bf = *reinterpret_cast<const u32x4*>(tb + daddr[ks & 3] + (ks >> 2) * 256);
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) P[g][ct] = X::mma(wreg[ks][ct], bf, P[g][ct]);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < M_; ++m) {
-                if (more) issue_x_piece(o0 + 16, cur ^ 1, (h0 / HG) * M_ + m);
-                float a[HG];
-#pragma unroll
-                for (int g = 0; g < HG; ++g) a[g] = 0.f;
-#pragma unroll
-                for (int c2 = 0; c2 < NCT / 2; ++c2) {
-                    const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (xaddr0 ^ (64 * c2)) + m * 16 * SB);
-                    float xf[8];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        xf[2 * i] = __uint_as_float(xv[i] << 16);
-                        xf[2 * i + 1] = __uint_as_float(xv[i] & 0xffff0000u);
-                    }
-#pragma unroll
-                    for (int g = 0; g < HG; ++g)
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) a[g] = fmaf(P[g][2 * c2 + (i >> 2)][i & 3], xf[i], a[g]);
-                }
-                // sum over the wave's four lane groups as a reduce-scatter (dsu_ws_kernel, NOBR): every lane ends with the
-                // total of head h0 + (lg & 1) and stores it (lanes 32 apart: the same value to the same word)
-                const unsigned int u0 = __float_as_uint(a[0]), u1 = __float_as_uint(a[1]);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(u0, u1, false, false);
-                const unsigned int us = __float_as_uint(__uint_as_float(r1[0]) + __uint_as_float(r1[1]));
-                const auto r2 = __builtin_amdgcn_permlane32_swap(us, us, false, false);
-                pw[(h0 + (lg & 1)) * 64 + m] = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
-            }
-        }
-        // partials written (the next step's do tile landed with the previous step's vmcnt(0): this barrier publishes both)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 2: softmax backward for (sample r16, head lg), all modalities in-lane; ds operands; u product
-        {
-            const float* pr = part + cur * PT + (lg * 16 + r16) * 4;
-            f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ww = 0; ww < 8; ++ww) da += *reinterpret_cast<const f32x4*>(pr + ww * PTW);      // fixed order
-            const int64_t b = o0 + r16;
-            const bool on = b < o_end;
-            float dw[M_];
-#pragma unroll
-            for (int m = 0; m < M_; ++m) dw[m] = p.d_attn_w ? dwb[m] : 0.f;
-            if (p.d_entropy) {                                     // eval mode: the entropy keeps its graph (ref :150-156)
-                const int64_t be = on ? b : o_end - 1;
-                float hsum = 0.f;
-#pragma unroll
-                for (int m = 0; m < M_; ++m) hsum -= xlogx(p.attn_w[be * M_ + m]);
-                const bool live = (hsum >= 0.f) && (hsum <= p.log_M);
-#pragma unroll
-                for (int m = 0; m < M_; ++m) dw[m] += live ? -(logf(p.attn_w[be * M_ + m]) + 1.0f) * p.d_entropy[be] : 0.f;
-            }
-            float dp[M_], dot = 0.f;
-#pragma unroll
-            for (int m = 0; m < M_; ++m) { dp[m] = da[m] + dw[m] * invH; dot += pmv[m] * dp[m]; }
-#pragma unroll
-            for (int m = 0; m < M_; ++m) {
-                const float d = on ? pmv[m] * (dp[m] - dot) : 0.f;
-                if (on && w == 0) p.dsbuf[(b * H + hbase + lg) * M_ + m] = d;
-                const unsigned short hi = X::from_f32(d);
-                const int sl = kslot(r16, m);
-                dsw_w[lg * DSROW + sl] = hi;
-                dsw_w[(HBL + lg) * DSROW + sl] = X::from_f32(d - X::to_f32(hi));
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's operand arrays are in LDS (its own reads follow)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < KU; ++ks) {
-            const u32x4 bh = *reinterpret_cast<const u32x4*>(smem + bh_off + 64 * ks);
-            const u32x4 bl = *reinterpret_cast<const u32x4*>(smem + bl_off + 64 * ks);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int a0 = ua[ks][0] < 0 ? (int)(zp - smem) + 64 * lg : cur * XT + (ua[ks][0] ^ (32 * ct));
-                const int a1 = ua[ks][1] < 0 ? (int)(zp - smem) + 64 * lg : cur * XT + (ua[ks][1] ^ (32 * ct));
-                const u32x4 af = tr_frag16(smem, a0, a1);
-                uacc[ct] = X::mma(af, bh, uacc[ct]);
-                uacc[ct] = X::mma(af, bl, uacc[ct]);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own slab + statistics of the next step landed
-#pragma unroll
-        for (int m = 0; m < M_; ++m) {
-            asm volatile("" : "+v"(pmv_n[m]), "+v"(dwb_n[m]));
-            pmv[m] = pmv_n[m]; dwb[m] = dwb_n[m];
-        }
-    }
-    // u slab of this row chunk: rows = the block's heads, lane (lg, r16 = local head) holds k = ncol0 + 16 ct + 4 lg .. + 3
-    if (r16 < HBL) {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-            *reinterpret_cast<f32x4*>(u_slab + ((int64_t)chunk_u * H + hbase + r16) * E + ncol0 + 16 * ct + 4 * lg) = uacc[ct];
-    }
-}
-
-template <int M_>
-int launch_dsu_slab(const BwdGArgs& a, float* u_slab, hipStream_t s) {
-    constexpr int XT = 8 * 16 * M_ * 128;
-    const size_t smem = (size_t)2 * XT + 256 + (size_t)3 * 16 * 512 + (size_t)2 * 8 * 4 * 16 * 4 * 4 + (size_t)8 * 2 * 4 * 72 * 2 + 8192 /* (ablation scratch) */;
-    const int groups = 2;
-    const int64_t chunks = 256 / groups;
-    int64_t rpb = (a.B + chunks - 1) / chunks;
-    rpb = (rpb + 15) / 16 * 16;
-    const int64_t nchunk = (a.B + rpb - 1) / rpb;
-    dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
-    auto kern = dsu_slab_kernel<M_>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
-    return (int)nchunk;
-}
+// (A second form of this kernel around WAVE-PRIVATE x slabs -- dsu_slab_kernel, round 4: one barrier per step instead of three,
+// every wave runs the softmax backward for all heads -- measured level with it, 118 against 113-120 us,
+// profiles/r04_c2_dsu_slab_ablation.txt; it left the product library in round 5: tools/micro/variants/aecf_gemm_ws_ablations.hip.)
 
 template <int KT, int KJ, int HK, int M_>
 int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
@@ -1326,24 +1025,18 @@ int launch_dsu_t(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     rpb = (rpb + 15) / 16 * 16;
     const int64_t nchunk = (a.B + rpb - 1) / rpb;
     dim3 grid(xcd_grid((unsigned)nchunk, (unsigned)groups)), block(512);
-    const int var = (KT / 4) % 2 == 0 ? env_dsu_var() : 0;        // (A/B: AECF_DEBUG=dsu_var=0|1|2)
-#define DSU_GO(V_)                                                                                                             \
-    {                                                                                                                          \
-        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false, V_>;                                                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);                                                      \
-        return (int)nchunk;                                                                                                    \
-    }
+    // dot phase: 16-byte x reads and branch-free partial dots (VAR 2) where the K-step count allows, else the 8-byte form (VAR 0)
+    constexpr int VAR = (KT / 4) % 2 == 0 ? 2 : 0;
     if (hilo) {                                                   // AECF_HILO_GRADS: P from do_hi + do_lo
-        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false, ((KT / 4) % 2 == 0 ? 2 : 0), true>;
+        auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false, VAR, true>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
         return (int)nchunk;
     }
-    if (var == 0) DSU_GO(0)
-    if (var == 1) DSU_GO(1)
-    DSU_GO(2)
-#undef DSU_GO
+    auto kern = dsu_ws_kernel<KT, KJ, HK, M_, false, VAR>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    kern<<<grid, block, smem, s>>>(a, u_slab, (int)rpb, (int)nchunk);
+    return (int)nchunk;
 }
 
 template <int KT, int HK, int M_>
@@ -1738,13 +1431,6 @@ static int launch_dsu_m(const BwdGArgs& a, float* u_slab, hipStream_t s) {
 int launch_dsu_ws(const BwdGArgs& a, float* u_slab, hipStream_t s) {
     if (dsu_ws_chunks(a) == 0) return 0;
     const int hk = a.hd / 32;
-    if (a.E == 512 && hk == 2 && a.M <= 3 && env_dsu_var() >= 3 && !a.do_lo) {           // the hot shape: wave-private slabs, one barrier per step
-        switch (a.M) {
-            case 1: return launch_dsu_slab<1>(a, u_slab, s);
-            case 2: return launch_dsu_slab<2>(a, u_slab, s);
-            default: return launch_dsu_slab<3>(a, u_slab, s);
-        }
-    }
 #define DSU_CASE(KT_)                                                   \
     switch (hk) {                                                       \
         case 1: return launch_dsu_m<KT_, 1>(a, u_slab, s);              \

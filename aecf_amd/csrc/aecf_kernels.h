@@ -191,7 +191,6 @@ struct ReduceSegs {
 bool env_no_ws();
 bool env_no_wide_tn();
 bool env_no_slab();
-int env_dsu_var();
 
 void launch_reduce_segments(const ReduceSegs& r, hipStream_t s);
 
