@@ -1,5 +1,5 @@
 """Phase timeline of gemm_tn_tr_wide_kernel (dW_v) at C2 from in-kernel shader-clock stamps (experiment build
--DAECF_TN_TIMELINE: tools/build_variant.sh tl "-DAECF_TN_TIMELINE" aecf_amd/csrc/aecf_gemm_tn_tr.hip; run with
+-DAECF_TN_TIMELINE: a scratch checkout with tools/micro/variants/aecf_gemm_tn_tr_ablations.hip (the round-4 source that carries the stamps) in place of aecf_gemm_tn_tr.hip, built with -DAECF_TN_TIMELINE; run with
 AECF_LIB_PATH=build/var/tl/libaecf_hip.so).  Stamps per step: 0 top, 1 after vmcnt(0), 2 probs in LDS (lgkmcnt), 3 after barrier 1,
 4 pooling issued, 5 pooled stores done (lgkmcnt), 6 after barrier 2, 7 after the MFMA phase."""
 import ctypes

@@ -1,5 +1,5 @@
 """Phase timeline of vproj_slab_kernel at C2 from in-kernel shader-clock stamps (experiment build -DAECF_WS_TIMELINE:
-tools/build_variant.sh wtl "-DAECF_WS_TIMELINE" aecf_amd/csrc/aecf_gemm_ws.hip; AECF_LIB_PATH=build/var/wtl/libaecf_hip.so).
+a scratch checkout with tools/micro/variants/aecf_gemm_ws_ablations.hip (the round-4 source that carries the stamps) in place of aecf_gemm_ws.hip, built with -DAECF_WS_TIMELINE; AECF_LIB_PATH=build/var/wtl/libaecf_hip.so).
 Stamps per 16-sample step: 0 top, 1 after (lgkmcnt + barrier), 2 after the softmax, 3 after the MFMA loop, 4 after vmcnt(0),
 5 after the next step's partial scores, 6 after the stores."""
 import ctypes
