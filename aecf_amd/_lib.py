@@ -135,6 +135,7 @@ _SYMBOLS = [
     ("aecf_rows_select", c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     ("aecf_front_pair", c_int, [c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("aecf_cast_f32_to_bf16", c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("aecf_adamw_step", c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                 c_float, c_float, c_float, c_void_p]),
     ("aecf_rows_split", c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -887,6 +887,18 @@ int aecf_rows_select(int64_t rows, int64_t row_bytes, const int32_t* route, cons
     return launch_status();
 }
 
+int aecf_cast_f32_to_bf16(int32_t n, const float* const* src, void* const* dst, const int64_t* numel, void* stream) {
+    if (n < 0 || n > 8) return AECF_ERR_BAD_DIMS;
+    if (n == 0) return AECF_OK;
+    if (!src || !dst || !numel) return AECF_ERR_NULL_POINTER;
+    for (int i = 0; i < n; ++i) {
+        if (numel[i] < 0) return AECF_ERR_BAD_DIMS;
+        if (numel[i] > 0 && (!src[i] || !dst[i])) return AECF_ERR_NULL_POINTER;
+    }
+    launch_cast_f32_bf16_multi(n, src, dst, numel, (hipStream_t)stream);
+    return launch_status();
+}
+
 int aecf_adamw_step(int32_t n, void* const* param, const void* const* grad, void* const* exp_avg, void* const* exp_avg_sq,
                     void* const* step, const int64_t* numel, void* ticket, float lr, float beta1, float beta2, float eps,
                     float weight_decay, void* stream) {

@@ -242,6 +242,7 @@ void launch_modality_frontend(int dtype, int64_t rows, int dim, const void* feat
                               uint8_t* present, hipStream_t s);
 void launch_transpose_rect(int dtype, const void* src, void* dst, int64_t R, int64_t C, hipStream_t s);
 void launch_cast_bf16_f32(const void* src, float* dst, int64_t n, hipStream_t s);     // 16-byte aligned src / dst
+int launch_cast_f32_bf16_multi(int n, const float* const* src, void* const* dst, const int64_t* numel, hipStream_t s);   // n <= 8
 
 // flash-style InfoNCE direction (aecf_nce_flash.hip): no [rows, cols] logits; optional entropy regulariser in the same call
 bool nce_flash_supported(int dtype, int d);

@@ -448,6 +448,47 @@ void launch_philox_uniforms(int64_t n, const PhiloxDraw& ph, float* out, hipStre
     philox_uniforms_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(n, ph, out);
 }
 
+// float32 -> bf16 (round to nearest even) of up to 8 tensors in ONE launch: the master-weight casts of a mixed-precision step
+// (blocks of 2048 elements dealt over the tensors in order; torch's multi-tensor copy hands a block 65536 elements: 21 us for
+// the 1 M parameters of the d = 512 layer against ~4 us here)
+struct CastJobs {
+    int n = 0;
+    const float* src[8];
+    unsigned short* dst[8];
+    int64_t numel[8];
+    int64_t first_block[9];
+};
+__global__ __launch_bounds__(256) void cast_f32_bf16_multi_kernel(CastJobs j) {
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < j.n && (int64_t)blockIdx.x >= j.first_block[i]) t = i;
+    const int64_t i0 = (((int64_t)blockIdx.x - j.first_block[t]) * 256 + threadIdx.x) * 8;
+    const float* src = j.src[t];
+    unsigned short* dst = j.dst[t];
+    const int64_t n = j.numel[t];
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    if (vec && i0 + 8 <= n) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + i0), b = *reinterpret_cast<const f32x4*>(src + i0 + 4);
+        *reinterpret_cast<u32x4*>(dst + i0) = u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+                                                    pack_bf16x2(b[2], b[3])};
+    } else {
+        for (int64_t k = i0; k < n && k < i0 + 8; ++k) dst[k] = Tr<BF16>::from_f32(src[k]);
+    }
+}
+
+int launch_cast_f32_bf16_multi(int n, const float* const* src, void* const* dst, const int64_t* numel, hipStream_t s) {
+    CastJobs j;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        j.src[j.n] = src[i]; j.dst[j.n] = (unsigned short*)dst[i]; j.numel[j.n] = numel[i]; j.first_block[j.n] = blocks;
+        if (numel[i] > 0) { blocks += (numel[i] + 2047) / 2048; ++j.n; }
+    }
+    if (blocks == 0) return 0;
+    cast_f32_bf16_multi_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(j);
+    return 1;
+}
+
 void launch_cast_bf16_f32(const void* src, float* dst, int64_t n, hipStream_t s) {
     if (n <= 0 || !src) return;
     cast_bf16_f32_kernel<<<dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s>>>((const unsigned short*)src, dst, n);

@@ -260,9 +260,12 @@ class _PoolFunction(torch.autograd.Function):
         _lib.check(facts[0], "aecf_pool_check")
         _, fwd_ws_bytes, bwd_ws_bytes, prep_bytes, wants_v, hilo_bytes = facts
         xc = x.contiguous()
-        qc = q.detach().reshape(E).to(dt).contiguous()
+        if casts is not None and len(casts) > 4 and casts[4] is not None:
+            qc = casts[4].reshape(E)           # (cast by the module's one multi-tensor launch, with the weights)
+        else:
+            qc = q.detach().reshape(E).to(dt).contiguous()
         if casts is not None:                  # activation-dtype copies of master weights, cached by the module
-            w_in_c, b_in_c, w_out_c, b_out_c = casts
+            w_in_c, b_in_c, w_out_c, b_out_c = casts[:4]
         else:
             w_in_c = w_in.detach().to(dt).contiguous()
             w_out_c = w_out.detach().to(dt).contiguous()
@@ -832,7 +835,7 @@ class MultimodalAttentionPool(nn.Module):
         the module is in eval mode under ``torch.no_grad()``: such writes do not move the parameter's version counter."""
         self._cast_cache.clear()
 
-    def _activation_dtype_params(self, dt: torch.dtype):
+    def _activation_dtype_params(self, dt: torch.dtype, query: Optional[torch.Tensor] = None):
         """Master weights kept in another dtype than the activations (float32 parameters, bf16 data): the kernels want
         them in the activation dtype.  Inference (eval mode, or no gradient recording) reuses the copies while the
         parameters' version counters and storage stand still; whenever the module trains they are remade on every forward:
@@ -840,19 +843,38 @@ class MultimodalAttentionPool(nn.Module):
         counter alone, and stale weights would go unnoticed.  ``invalidate_cast_cache()`` covers ``.data`` writes in eval."""
         a = self.attention
         reuse = not (self.training and torch.is_grad_enabled())
+        named = (("w_in", a.in_proj_weight), ("b_in", a.in_proj_bias), ("w_out", a.out_proj.weight), ("b_out", a.out_proj.bias))
+        if not reuse:
+            # training: ONE cast launch for the four of them + the query (aecf_cast_f32_to_bf16; one torch launch each was ~22 us
+            # of a 0.7 ms step, and torch's multi-tensor copy takes as long: it hands a block 65536 elements) into fresh
+            # allocations (the backward keeps them: a later forward must not write over what an earlier one saved)
+            srcs = [p.detach() for _, p in named if p is not None]
+            ride = query is not None and query.dtype != dt and query.is_contiguous()      # the shared query travels along
+            if ride:
+                srcs.append(query.detach())
+            dsts = [torch.empty(p.shape, dtype=dt, device=p.device) for p in srcs]
+            if (dt == torch.bfloat16 and all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() for p in srcs)):
+                n = len(srcs)
+                vp = ctypes.c_void_p
+                _lib.check(_lib.load().aecf_cast_f32_to_bf16(
+                    n, (vp * n)(*[p.data_ptr() for p in srcs]), (vp * n)(*[d.data_ptr() for d in dsts]),
+                    (ctypes.c_int64 * n)(*[p.numel() for p in srcs]), _stream()), "aecf_cast_f32_to_bf16")
+            else:
+                torch._foreach_copy_(dsts, srcs)
+            it = iter(dsts)
+            return tuple(None if p is None else next(it) for _, p in named) + ((dsts[-1],) if ride else (None,))
         out = []
-        for name, p in (("w_in", a.in_proj_weight), ("b_in", a.in_proj_bias), ("w_out", a.out_proj.weight),
-                        ("b_out", a.out_proj.bias)):
+        for name, p in named:
             if p is None:
                 out.append(None)
                 continue
             key = (p._version, p.data_ptr(), p.device, dt)
-            hit = self._cast_cache.get(name) if reuse else None
+            hit = self._cast_cache.get(name)
             if hit is None or hit[0] != key:
                 hit = (key, p.detach().to(dt).contiguous())
                 self._cast_cache[name] = hit
             out.append(hit[1])
-        return tuple(out)
+        return tuple(out) + (None,)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: Optional[torch.Tensor] = None,
                 key_padding_mask: Optional[torch.Tensor] = None, attn_mask: Optional[torch.Tensor] = None,
@@ -989,7 +1011,7 @@ class MultimodalAttentionPool(nn.Module):
             x, q_base, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, kpm, mask_u,
             self.num_heads, mask_mode, 1 if cm is None else int(cm.min_active),
             0.15 if cm is None else float(cm.base_mask_prob), 0.7 if cm is None else float(cm.entropy_target), 1e-8,
-            False, tgt_value, self._activation_dtype_params(x.dtype) if a.in_proj_weight.dtype != x.dtype else None, side,
+            False, tgt_value, self._activation_dtype_params(x.dtype, q_base) if a.in_proj_weight.dtype != x.dtype else None, side,
             philox, opts)
 
         dt = x.dtype

@@ -386,6 +386,12 @@ int aecf_front_pair(int64_t rows, int32_t dim_a, int32_t dim_b, int32_t dtype, c
 int aecf_rows_split(int64_t rows, int64_t row_bytes, const int32_t* route, const void* src, void* const* dst,
                     void* stream);
 
+/* float32 -> bf16 (round to nearest even) of up to 8 tensors in one launch: the activation-dtype copies of float32 MASTER
+ * parameters a mixed-precision step hands to aecf_pool_forward (w_in, b_in, w_out, b_out, query; ABI v9).  What
+ * `p.to(torch.bfloat16)` does per tensor (ref: the reference trains in one dtype; torch's autocast makes these copies), as one
+ * launch of 2048-element blocks.  src[i] / dst[i]: device pointers, numel[i] elements each; host arrays of length n <= 8. */
+int aecf_cast_f32_to_bf16(int32_t n, const float* const* src, void* const* dst, const int64_t* numel, void* stream);
+
 /* ---- the example trainer's optimiser step (ref xrays/train_xrays_example.py:322-323, 376: torch.optim.AdamW) ----
  * AdamW (decoupled weight decay, no amsgrad) over n float32 tensors in one launch per 24 tensors: arrays of n device
  * pointers (param, grad, exp_avg, exp_avg_sq: numel[i] floats each; step[i]: ONE float, the number of steps taken so far,

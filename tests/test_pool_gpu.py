@@ -1000,3 +1000,25 @@ def test_embed_sizes_no_kernel_tiles_are_served_by_head_padding(E, H, dtype, tol
     for got, want in ((a.in_proj_weight.grad, b["dw_in"]), (a.in_proj_bias.grad, b["db_in"]),
                       (a.out_proj.weight.grad, b["dw_out"]), (a.out_proj.bias.grad, b["db_out"])):
         assert rel_err(c(got), want) < 2 * tol
+
+
+def test_master_weight_cast_is_one_launch_and_rounds_like_torch():
+    """aecf_cast_f32_to_bf16 (ABI v9): the activation-dtype copies of float32 master parameters, several tensors in one launch,
+    bit-equal to `p.to(torch.bfloat16)` -- sizes that end inside a 2048-element block, an empty tensor, an unaligned view."""
+    import ctypes
+    from aecf_amd import _lib
+    from aecf_amd.layer import _stream
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(9)
+    base = torch.randn(5000, device=dev, generator=g)
+    srcs = [torch.randn(1536, 512, device=dev, generator=g), torch.randn(1536, device=dev, generator=g), torch.randn(7, device=dev, generator=g),
+            torch.empty(0, device=dev), base[1:4098], torch.randn(1, 1, 512, device=dev, generator=g) * 1e-20]
+    dsts = [torch.full(s_.shape, float("nan"), dtype=torch.bfloat16, device=dev) for s_ in srcs]
+    n = len(srcs)
+    vp = ctypes.c_void_p
+    _lib.check(_lib.load().aecf_cast_f32_to_bf16(n, (vp * n)(*[s_.data_ptr() for s_ in srcs]), (vp * n)(*[d_.data_ptr() for d_ in dsts]),
+                                                  (ctypes.c_int64 * n)(*[s_.numel() for s_ in srcs]), _stream()), "aecf_cast_f32_to_bf16")
+    torch.cuda.synchronize()
+    for s_, d_ in zip(srcs, dsts):
+        assert torch.equal(d_, s_.to(torch.bfloat16)), tuple(s_.shape)
+    assert _lib.load().aecf_cast_f32_to_bf16(9, None, None, None, None) == -1
