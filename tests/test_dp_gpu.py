@@ -143,6 +143,19 @@ def _worker(rank, world, port, backend, dtype, q):
         for a_, p in zip(two, params):
             err = (a_.float() - p.grad.float()).abs().max().item() / max(p.grad.float().abs().max().item(), 1e-12)
             assert err < tol2, err
+        # micro-batches: two backward() calls accumulate into p.grad before ONE collective (with bf16 parameters and deferred
+        # rounding the second call has to give the first one's tensors their values before autograd adds to them)
+        for p in params:
+            p.grad = None
+        st.defer_rounding = dtype == torch.bfloat16
+        _run_shard(query, pool, x[lo:mid], dy[lo:mid], u[:mid - lo], dev, float(world))
+        _run_shard(query, pool, x[mid:hi], dy[mid:hi], u[mid - lo:], dev, float(world))
+        dp.all_reduce_grads(params)
+        torch.cuda.synchronize()
+        st.defer_rounding = False
+        for a_, p in zip(plain, params):
+            err = (a_.float() - p.grad.float()).abs().max().item() / max(a_.float().abs().max().item(), 1e-12)
+            assert err < tol2, ("micro-batches", err)
         # a backward that starts with gradients already set (accumulation): the hook is not installed, finish() reduces plainly
         overlap = dp.GradOverlap(params=params)
         with overlap:
