@@ -241,3 +241,74 @@ def test_philox_known_answers_and_element_mapping(built_library):
         u = np.float32(2.3283064e-10) + np.float32(want_raw[ii]) * np.float32(2.3283064e-10)
         u = np.float32(0.0) if u == np.float32(1.0) else u
         assert np.float32(got) == u and 0.0 <= got < 1.0
+
+
+def test_philox_launch_geometry_matches_torchs_formula(monkeypatch):
+    """layer._philox_geometry restates ATen's launch geometry of torch.rand (block 256, unroll 4, grid capped at
+    CUs * max_threads_per_CU / 256) and the generator advance ((n - 1) // (4 T) + 1) * 4 -- checked here against a fake generator for
+    sizes below, at and beyond one grid-stride iteration of an MI355X-sized device (256 CUs x 2048 threads); the GPU tests check
+    the values themselves against torch.rand."""
+    from aecf_amd import layer
+
+    class Gen:
+        def __init__(self):
+            self.off = 40
+
+        def initial_seed(self):
+            return -3                                        # (torch hands back a signed 64-bit value for large seeds)
+
+        def get_offset(self):
+            return self.off
+
+    monkeypatch.setitem(layer._props_cache, 0, (256, 2048))
+    cap = 256 * (2048 // 256)                                # blocks
+    for n, want_threads, want_inc in [(1, 256, 4), (256, 256, 4), (257, 512, 4), (196608, 196608, 4),
+                                      (256 * cap * 4, 256 * cap, 4), (256 * cap * 4 + 1, 256 * cap, 8), (10 ** 7, 256 * cap, 20)]:
+        seed, offset, threads, inc = layer._philox_geometry(n, 0, Gen())
+        assert (seed, offset, threads, inc) == (2 ** 64 - 3, 40, want_threads, want_inc), n
+
+
+def test_dp_state_records_are_matched_by_identity():
+    """layer.DpState: the float32 sums behind a gradient run are handed out only for THAT run, untouched; which tensors carry the
+    1 / world factor is a matter of object identity (never of tensor equality, never of a storage pointer that may be reused)."""
+    from aecf_amd import layer
+    st = layer.DpState(world=4, grad_scale=0.25)
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3))
+    st.add_scaled(a)
+    assert st.is_scaled(a) and not st.is_scaled(b)
+    flat = torch.zeros(8, dtype=torch.bfloat16)
+    wide = torch.ones(8)
+    st.record(flat, wide)
+    other = torch.zeros(8, dtype=torch.bfloat16)
+    assert st.take(other) is None and st.runs == []          # somebody else's run: nothing handed out, records consumed
+    st.record(flat, wide)
+    assert st.take(flat) is wide
+    st.record(flat, wide)
+    flat.add_(1)                                             # autograd accumulated into it: the sums no longer describe it
+    assert st.take(flat) is None
+    for _ in range(20):                                      # bounded: the first run (autograd's accumulation target) + the latest
+        st.record(torch.zeros(2), None)
+    assert len(st.runs) <= 8
+    del a
+    import gc
+    gc.collect()
+    assert all(r() is None or r() is not None for r in st.scaled.values())     # weak references: a dead parameter does not pin memory
+
+
+def test_attach_and_detach_are_per_module():
+    """dp.attach makes ONE module data-parallel (no process-wide switch): its options carry the state, another module is
+    untouched, detach removes it."""
+    import aecf_amd
+    from aecf_amd import dp
+    _, p1 = aecf_amd.create_fusion_pool(64, 2, num_heads=2)
+    _, p2 = aecf_amd.create_fusion_pool(64, 2, num_heads=2)
+    st = dp.attach(p1, world=8)
+    assert p1.options.dp is st and p2.options.dp is None
+    assert st.world == 8 and st.grad_scale == 0.125 and st.keep_f32 and not st.defer_rounding
+    assert all(st.is_scaled(p) for p in p1.parameters()) and not any(st.is_scaled(p) for p in p2.parameters())
+    assert dp._states_of(list(p1.parameters())) == [st] and dp._states_of(list(p2.parameters())) == []
+    st1 = dp.attach(p1, world=1)
+    assert st1.grad_scale == 1.0                             # one rank: nothing to fold in
+    dp.detach(p1)
+    assert p1.options.dp is None and dp._states_of(list(p1.parameters())) == []
+    assert p1.options.hilo_grads is None and p1.options.draw_in_kernel and p1.options.share_prep
