@@ -459,6 +459,8 @@ def main():
                          "group -- rehearses the RCCL call (and, with --graph, its capture) on a one-GPU box")
     ap.add_argument("--no-strong-graph", action="store_true",
                     help="N>1 weak scaling: do not attempt the graph-captured form of the strong-scaling point")
+    ap.add_argument("--rows", type=int, default=0,
+                    help="pool configurations: rows per GPU instead of the config's batch (strong-scaling shards on one GPU)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=30.0, help="budget of the CPU-oracle leg")
     args = ap.parse_args()
     globals()["SETTLE_SECONDS"] = args.settle_seconds
@@ -500,6 +502,8 @@ def main():
     device = torch.device("cuda", dev_index)
     from aecf_amd import dp
     Bc, M, E, H, dtype, p = CONFIGS[args.config]
+    if args.rows > 0:
+        Bc = args.rows
     if args.scaling == "strong" and world > 1:
         lo, hi = dp.shard_bounds(Bc, rank, world)
         B, B_global = hi - lo, Bc
