@@ -13,7 +13,7 @@
 // Same tile images, transposed LDS reads (ds_read_b64_tr_b16), LDS-DMA and one-step-ahead operand fetches as
 // aecf_gemm_tn_tr.hip.  What differs is the step: 32 batch rows (one MFMA K-step) instead of 64, because a step now holds
 // twice the tiles -- pooled product: lhs hi + lo [32][128] x 2 buffers = 32 KB, pooled hi + lo x 2 head slots = 32 KB.
-// Measured at the headline shape (profiles/r05_c2_hilo_time.txt): dW_v 92 -> 152 us, dW_o 46 -> 75 us, against 310 / 107 us
+// Measured at the headline shape (profiles/r05_c2_hilo_time.txt): dW_v 92 -> 152 us, dW_o 46 -> 77 us, against 310 / 107 us
 // for the round-4 launches; float32-stored parameter gradients 3 - 5e-6 of fp32 math.
 #include <stdlib.h>
 
@@ -418,7 +418,7 @@ int hilo_slots_128(int E, int hd) {               // head slots of the widest al
 
 // shapes of the one-launch hi + lo products: E a multiple of 128 (128 x 128 block tiles), at most 4 head slots per 128 rows,
 // M <= 3 (the 128-VGPR budget of the pooled kernel), rows_per_split a multiple of 32
-bool gemm_tn_hilo_supported(const GemmTnArgs& a) {
+bool gemm_tn_hilo_supported(const GemmTnArgs& a) {               // (the plain product needs rhs_lo at launch, the pooled one lhs_lo)
     if (a.E % 128 != 0 || a.M < 1 || a.M > 3 || (a.Ej > 0 && a.Ej != a.E) || a.rows_per_split % HRB != 0) return false;
     return !a.pooled || hilo_slots_128(a.E, a.hd) != 0;
 }
@@ -426,20 +426,13 @@ bool gemm_tn_hilo_supported(const GemmTnArgs& a) {
 void launch_gemm_tn_hilo(const GemmTnArgs& a, hipStream_t s) {
     if (!a.pooled) {
         // the plain product with both rhs tiles of a step (o_hi, o_lo): a ring of three 24 KB stages, two blocks per CU (75 us at
-        // the headline shape; two stages: 85).  Without rhs_lo the same kernel runs the default product -- kept for shapes
-        // tests exercise; the default path's 64-row two-buffer kernel is faster there (46 against 53 us)
+        // the headline shape; two stages: 85).  (The same kernel without the low tile -- the default product on 32-row steps with
+        // four stages -- measured 53 us against the 46 us of the default path's 64-row two-buffer kernel: not instantiated.)
         dim3 grid(xcd_grid((unsigned)a.splits, (unsigned)((a.E / 128) * (a.E / 128)))), block(512);
-        if (a.rhs_lo) {
-            const size_t smem = (size_t)3 * 3 * HR_TILE;
-            auto kern = gemm_tn_ring_kernel<true, 3>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            kern<<<grid, block, smem, s>>>(a);
-        } else {
-            const size_t smem = (size_t)4 * 2 * HR_TILE;
-            auto kern = gemm_tn_ring_kernel<false, 4>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            kern<<<grid, block, smem, s>>>(a);
-        }
+        const size_t smem = (size_t)3 * 3 * HR_TILE;
+        auto kern = gemm_tn_ring_kernel<true, 3>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        kern<<<grid, block, smem, s>>>(a);
         return;
     }
     const bool two128 = hilo_slots_128(a.E, a.hd) == 2;
