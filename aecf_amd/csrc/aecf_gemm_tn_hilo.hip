@@ -117,7 +117,11 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_hilo_pooled_kernel(GemmTnArgs 
     const unsigned int ldl = (unsigned)E * 2u;
     const unsigned int ldr = (unsigned)M_ * (unsigned)E * 2u;
 
-    const int prow = threadIdx.x >> 4, pc = threadIdx.x & 15;
+    // pooling role: 8 consecutive lanes = two adjacent rows x four chunks, so that one ds_write_b128 beat covers both 64-byte
+    // halves of the 128-byte bank window (row-major roles -- 8 lanes = 8 chunks of one row -- hit the same half twice: a quarter
+    // of this kernel's LDS cycles were bank conflicts, profiles/r05_c2_f32params_sq_counters.csv; 158 -> 155 us)
+    const int gq = lane >> 3, i8 = lane & 7;
+    const int prow = 4 * w + 2 * (gq >> 2) + (i8 >> 2), pc = 4 * (gq & 3) + (i8 & 3);
     const unsigned int prow_off = (unsigned)prow * ldr;
     u32x4 Rb[M_];
     float plr = 0.f;
