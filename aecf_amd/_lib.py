@@ -19,6 +19,7 @@ AECF_F32 = 1
 AECF_PRECISE = 1
 AECF_DRAW_UNIFORMS = 2
 AECF_HILO_GRADS = 4
+AECF_PREP_READY = 8
 AECF_FWD_STAGES = 4
 AECF_BWD_STAGES = 8
 

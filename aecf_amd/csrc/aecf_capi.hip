@@ -43,7 +43,7 @@ FwdWs fwd_layout(const aecf_pool_desc* d) {
 // what the backward derives from the parameters alone; lives at the head of the backward workspace or, when the caller
 // passes saved_prep, in that buffer (filled by the forward's preparation launch)
 struct PrepWs {
-    size_t qs, a_f32, a_hi, a_lo, wvt, wot, wvt_frag, wot_frag, total;
+    size_t qs, a_f32, a_hi, a_lo, wvt, wot, wvt_frag, wot_frag, wv_frag, wo_frag, total;
 };
 PrepWs prep_layout(const aecf_pool_desc* d) {
     PrepWs w;
@@ -57,6 +57,8 @@ PrepWs prep_layout(const aecf_pool_desc* d) {
     w.wot = off;    off = align_up(off + E * E * es);
     w.wvt_frag = off; off = align_up(off + E * E * es);
     w.wot_frag = off; off = align_up(off + E * E * es);
+    w.wv_frag = off; off = align_up(off + E * E * es);       // the FORWARD's fragment copies (ABI v9: with saved_prep they live here too,
+    w.wo_frag = off; off = align_up(off + E * E * es);       //  so that a forward can reuse a whole preparation: AECF_PREP_READY)
     w.total = off;
     return w;
 }
@@ -283,6 +285,8 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     if (precise && a->workspace_bytes < precise_fwd_layout(d).total) return AECF_ERR_WORKSPACE;
     if (!a || !a->x || !a->query || !a->w_in || !a->w_out || !a->y || !a->attn_w || !a->saved_probs || !a->workspace)
         return AECF_ERR_NULL_POINTER;
+    const bool prep_ready = (a->flags & AECF_PREP_READY) != 0;
+    if (prep_ready && !a->saved_prep) return AECF_ERR_NULL_POINTER;
     const bool draw = d->mask_mode == 1 && !a->uniforms && (a->flags & AECF_DRAW_UNIFORMS);
     if (d->mask_mode == 1 && !a->uniforms && !draw) return AECF_ERR_NULL_POINTER;
     if (draw && (a->philox_threads == 0 || a->philox_threads % 256 != 0 || a->philox_offset % 4 != 0 || a->philox_element0 < 0))
@@ -310,8 +314,8 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     FragJobs fj;
     if (frag) {
         fj.n = 2;
-        fj.src[0] = (const char*)a->w_in + (size_t)2 * E * E * es; fj.dst[0] = ws + L.wv_frag; fj.transposed[0] = 0;
-        fj.src[1] = a->w_out;                                      fj.dst[1] = ws + L.wo_frag; fj.transposed[1] = 0;
+        fj.src[0] = (const char*)a->w_in + (size_t)2 * E * E * es; fj.dst[0] = pb ? pb + P.wv_frag : ws + L.wv_frag; fj.transposed[0] = 0;
+        fj.src[1] = a->w_out;                                      fj.dst[1] = pb ? pb + P.wo_frag : ws + L.wo_frag; fj.transposed[1] = 0;
         if (pb) {
             fj.n = 4;
             fj.src[2] = fj.src[0]; fj.dst[2] = pb + P.wvt_frag; fj.transposed[2] = 1;
@@ -319,8 +323,11 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
         }
     }
     const char* w_v_src = (const char*)a->w_in + (size_t)2 * E * E * es;
-    launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, a_hi, a_lo, pb ? w_v_src : nullptr,
-                    pb ? pb + P.wvt : nullptr, pb ? a->w_out : nullptr, pb ? pb + P.wot : nullptr, E, H, fj, s);
+    // (AECF_PREP_READY: saved_prep still holds the preparation of these very parameters -- an inference loop, gradient
+    //  accumulation over micro-batches: nothing to launch)
+    if (!prep_ready)
+        launch_prep_all(d->dtype, a->w_in, a->b_in, a->query, scale, qs, a_f32, a_hi, a_lo, pb ? w_v_src : nullptr,
+                        pb ? pb + P.wvt : nullptr, pb ? a->w_out : nullptr, pb ? pb + P.wot : nullptr, E, H, fj, s);
     mark(ev, 1, s);
 
     GateArgs g;
@@ -340,7 +347,7 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
     v.bias = a->b_in ? (const char*)a->b_in + (size_t)2 * E * es : nullptr;
     v.c = o; v.probs = a->saved_probs; v.R = d->batch; v.N = E; v.K = E; v.lda = (int64_t)M * E;
     v.M = M; v.H = H; v.hd = hd; v.pooled = 1; v.out_f32 = precise ? 1 : 0; v.v_out = precise ? nullptr : a->saved_v;
-    if (frag) v.w_frag = ws + L.wv_frag;
+    if (frag) v.w_frag = pb ? pb + P.wv_frag : ws + L.wv_frag;
     const bool hilo = (a->flags & AECF_HILO_GRADS) != 0;
     if (hilo) {
         if (precise || !hilo_supported(d)) return AECF_ERR_UNSUPPORTED;
@@ -398,7 +405,7 @@ int pool_forward_on(const aecf_pool_desc* d, const aecf_pool_fwd_args* a, hipStr
         mark(ev, 4, s);
         return launch_status();
     }
-    if (frag) y.w_frag = ws + L.wo_frag;
+    if (frag) y.w_frag = pb ? pb + P.wo_frag : ws + L.wo_frag;
     // the entropy regulariser's final sum rides in the out-projection launch where the weight-stationary kernel runs it
     // (its first block adds the statistics kernel's partial sums: no launch of its own), else it is one small launch
     const bool want_loss = ent_partial && a->ent_loss;

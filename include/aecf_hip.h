@@ -162,6 +162,12 @@ typedef struct aecf_pool_fwd_args {
  * gradients are float32-stored (float32 master weights under bf16 activations); with bf16 parameters the gradient's own
  * rounding (2^-9) hides what the flag buys. */
 #define AECF_HILO_GRADS 4
+/* AECF_PREP_READY (forward only, with saved_prep; ABI v9): saved_prep already holds the preparation an earlier forward made from
+ * these very parameters and this query (same embed_dim / num_heads / dtype; the batch may differ): the preparation launch is
+ * skipped.  For loops in which the parameters provably stand still -- inference, gradient accumulation over micro-batches.  The
+ * caller is responsible for "unchanged" (the Python layer keys its cache on the parameters' version counters and storage, in
+ * eval mode / without gradient recording only). */
+#define AECF_PREP_READY 8
 
 /* Backward (autograd transpose of the above). */
 typedef struct aecf_pool_bwd_args {

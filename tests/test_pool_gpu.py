@@ -1022,3 +1022,67 @@ def test_master_weight_cast_is_one_launch_and_rounds_like_torch():
     for s_, d_ in zip(srcs, dsts):
         assert torch.equal(d_, s_.to(torch.bfloat16)), tuple(s_.shape)
     assert _lib.load().aecf_cast_f32_to_bf16(9, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_inference_reuses_the_preparation_until_a_parameter_moves(dtype):
+    """AECF_PREP_READY (ABI v9): in eval mode / without gradient recording the module keeps what the kernels derive from the
+    parameters alone and skips the preparation launch while the parameters' version counters and storage stand still -- same
+    bits as a fresh preparation, for any batch size; an in-place parameter update (version counter) or invalidate_cast_cache()
+    (writes through .data) remake it; training with gradients never uses the cache."""
+    import aecf_amd
+    dev = _dev()
+    E, H, M = 512, 8, 3
+    torch.manual_seed(3)
+    query, pool = aecf_amd.create_fusion_pool(E, M, num_heads=H)
+    pool = pool.to(dev, dtype).eval()
+    query = query.detach().to(dev, dtype)
+    x1 = torch.randn(300, M, E, device=dev).to(dtype)
+    x2 = torch.randn(77, M, E, device=dev).to(dtype)
+
+    def fresh(x):
+        pool._prep_cache = None
+        with torch.no_grad():
+            return pool(query.expand(x.shape[0], -1, -1), x, return_info=True)
+
+    with torch.no_grad():
+        want1, winfo1 = fresh(x1)
+        assert pool._prep_cache is not None
+        buf = pool._prep_cache[1]
+        got1, info1 = pool(query.expand(300, -1, -1), x1, return_info=True)          # cached preparation
+        assert pool._prep_cache[1] is buf
+        got2, _ = pool(query.expand(77, -1, -1), x2, return_info=True)               # another batch size, same buffer
+        assert pool._prep_cache[1] is buf
+    assert torch.equal(got1, want1) and torch.equal(info1["attention_weights"], winfo1["attention_weights"])
+    assert torch.equal(got2, fresh(x2)[0])
+    # an in-place update moves the version counter: the next call prepares again and sees the new weights
+    with torch.no_grad():
+        pool.attention.out_proj.weight.mul_(0.5)
+        pool.attention.out_proj.bias.mul_(0.5)
+        half, _ = pool(query.expand(300, -1, -1), x1, return_info=True)
+    assert pool._prep_cache[1] is not buf
+    assert torch.allclose(half.float(), want1.float() * 0.5, rtol=2e-2, atol=1e-3)
+    # a write through .data is invisible to the version counter: invalidate_cast_cache() is the documented way
+    pool.attention.out_proj.weight.data.mul_(2.0)
+    pool.attention.out_proj.bias.data.mul_(2.0)
+    pool.invalidate_cast_cache()
+    with torch.no_grad():
+        back, _ = pool(query.expand(300, -1, -1), x1, return_info=True)
+    assert torch.allclose(back.float(), want1.float(), rtol=2e-2, atol=1e-3)
+    # training with gradients: never the cache (optimizers may step through .data)
+    pool.train()
+    before = pool._prep_cache
+    xg = x1.clone().requires_grad_(True)
+    out, _ = pool(query.expand(300, -1, -1), xg, return_info=True)
+    out.float().sum().backward()
+    assert pool._prep_cache is before and xg.grad is not None
+    # eval mode WITH a backward: the cached buffer serves the backward too
+    pool.eval()
+    xg2 = x1.clone().requires_grad_(True)
+    o_a, _ = pool(query.expand(300, -1, -1), xg2, return_info=True)
+    o_a.float().sum().backward()
+    pool._prep_cache = None
+    xg3 = x1.clone().requires_grad_(True)
+    o_b, _ = pool(query.expand(300, -1, -1), xg3, return_info=True)
+    o_b.float().sum().backward()
+    assert torch.equal(o_a, o_b) and torch.equal(xg2.grad, xg3.grad)
