@@ -1,5 +1,5 @@
 #!/bin/bash
-# every bench.py mode once (sanity after the round's host-side changes)
+# tools/gpu_jobs/bench_modes.sh: every bench.py mode once (sanity after host-side changes)
 out=gpurun_out
 summ='import sys,json; l=json.loads(sys.stdin.read()); print(sys.argv[1], "ok", round(l["ms_per_step"],4), l["n_gpus"], l.get("collective_ms"), (l.get("strong_scaling") or {}).get("ms_per_step"))'
 timeout -k 10 300 python bench.py --config c3 --contrastive --steps 20 --warmup 5 --no-cpu-baseline 2>$out/v1.err | tee $out/r05_c3nce_bench.json | python -c "$summ" c3_contrastive || tail -5 $out/v1.err
