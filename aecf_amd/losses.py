@@ -21,6 +21,17 @@ from . import _lib, dp
 from .layer import _DTYPES, _ptr, _require_device, _stream, CurriculumMasking
 
 
+def _plus(total: torch.Tensor, term: torch.Tensor) -> torch.Tensor:
+    """total + term for two loss scalars whose dtypes may differ (a float32 InfoNCE term, a bf16 entropy regulariser): the
+    addend is brought to the sum's dtype first.  torch's mixed-dtype elementwise kernel (the run-time cast variant) takes ~41 us
+    for ONE element on this ROCm build against ~7 us for a same-dtype add (tools/debug/scalar_add_time.py) -- 1.4 % of the
+    configs[2] step for a scalar."""
+    if term.dtype != total.dtype and term.dim() == 0 and total.dim() == 0:
+        term = term.to(torch.promote_types(total.dtype, term.dtype))
+        total = total.to(term.dtype)
+    return total + term
+
+
 class _L2Norm(torch.autograd.Function):
     """aecf_l2norm_forward / _backward: rows -> unit norm."""
 
@@ -219,11 +230,11 @@ def contrastive_entropy_loss(za: torch.Tensor, zb: torch.Tensor, masking: Curric
     if _sym_supported(za, temperature, za.shape[0]):
         l_nce, l_ent = _NceSymmetric.apply(na, nb, entropy, 0, float(temperature), coef, None, int(seq_len),
                                            float(masking.entropy_target))
-        return contrastive_weight * l_nce + entropy_weight * l_ent.to(za.dtype)
+        return _plus(contrastive_weight * l_nce, entropy_weight * l_ent.to(za.dtype))
     l_ab, l_ent = _LossDirection.apply(na, nb, entropy, 0, float(temperature), coef, int(seq_len),
                                        float(masking.entropy_target))
     l_ba = _NceDirection.apply(nb, na, 0, float(temperature), coef, _stream_form(nb, na.shape[0]))
-    return contrastive_weight * (l_ab + l_ba) + entropy_weight * l_ent.to(za.dtype)
+    return _plus(contrastive_weight * (l_ab + l_ba), entropy_weight * l_ent.to(za.dtype))
 
 
 def gathered_contrastive_entropy_loss(za: torch.Tensor, nb_all: torch.Tensor, row_offset: int, masking: CurriculumMasking,
@@ -243,7 +254,7 @@ def gathered_contrastive_entropy_loss(za: torch.Tensor, nb_all: torch.Tensor, ro
     seq_len = masking._last_seq_len if hasattr(masking, "_last_seq_len") else 2
     l_nce, l_ent = _NceSymmetric.apply(na, nb_all, entropy, int(row_offset), float(temperature), coef, group, int(seq_len),
                                        float(masking.entropy_target))
-    return contrastive_weight * l_nce + entropy_weight * l_ent.to(za.dtype)
+    return _plus(contrastive_weight * l_nce, entropy_weight * l_ent.to(za.dtype))
 
 
 def l2_normalize(z: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
@@ -307,7 +318,7 @@ def fusion_objective(task_loss: torch.Tensor, masking: Optional[CurriculumMaskin
     """task + entropy_weight * entropy_loss(entropy) [ref README.md:205-208] + contrastive_weight * info_nce(za, zb)."""
     total = task_loss
     if masking is not None and entropy is not None:
-        total = total + entropy_weight * masking.entropy_loss(entropy)
+        total = _plus(total, entropy_weight * masking.entropy_loss(entropy))
     if za is not None and zb is not None:
-        total = total + contrastive_weight * info_nce(za, zb, temperature, group)
+        total = _plus(total, contrastive_weight * info_nce(za, zb, temperature, group))
     return total

@@ -382,11 +382,13 @@ class GraphedTrainStep:
 
         ``tune_gemm``: the nn.Linear layers around the pool run on torch's BLAS dispatch, whose default pick for a batch of 64
         is a 256 x 64 macro-tile kernel of 26-33 us per GEMM (profiles/r04_c4_notes.md); with this flag torch's TunableOp times
-        the rocBLAS / hipBLASLt candidates for each shape during the warm-up steps (process-wide switch, left enabled with
-        tuning off, so the capture and later calls use the recorded picks and nothing is tuned under capture)."""
+        the rocBLAS / hipBLASLt candidates for each shape during the warm-up steps; tuning is off during the capture (nothing is
+        timed under capture), the picks are baked into the captured graph, and the process-wide switches are handed back as they
+        were found afterwards."""
         model.static_routing = True
         if tune_gemm:
             import torch.cuda.tunable as tunable
+            prev_tunable = (tunable.is_enabled(), tunable.tuning_is_enabled())
             tunable.enable(True)
             tunable.tuning_enable(True)
             if hasattr(tunable, "write_file_on_exit"):
@@ -417,6 +419,9 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._step()
+        if tune_gemm:                                        # the picks are baked into the graph: hand the process-wide switches back
+            tunable.tuning_enable(prev_tunable[1])
+            tunable.enable(prev_tunable[0])
         # restore IN PLACE (the graph holds the addresses of the parameters and of the optimizer's state tensors)
         with torch.no_grad():
             for k, v in model.state_dict().items():
