@@ -596,7 +596,7 @@ def main():
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if dp_on else "global"):
             eager_step()
 
         def one_step():
@@ -705,7 +705,8 @@ def main():
                         strong_eager()
                 torch.cuda.current_stream().wait_stream(side)
                 captured = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(captured):
+                # (thread_local: RCCL's proxy / watchdog threads may touch the runtime while this thread captures)
+                with torch.cuda.graph(captured, capture_error_mode="thread_local"):
                     strong_eager()
             except Exception as e:                        # noqa: BLE001
                 captured, why = None, f"{type(e).__name__}: {str(e)[:120]}"
