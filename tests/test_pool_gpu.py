@@ -102,11 +102,20 @@ def test_pool_bf16_matches_fp32_math(name):
         assert errs[k] < bound, (name, k, errs[k], bound)
 
 
-def _hot_case(seed, dtype):
-    """Seeded inputs at the headline shape (d=512, 8 heads, M=3), module path, fp32 truth from the pinned oracle."""
+def _hot_case(seed, dtype, x_scale=1.0, dy_scale=1.0):
+    """Seeded inputs at the headline shape (d=512, 8 heads, M=3), module path, fp32 truth from the pinned oracle.
+    x_scale / dy_scale: powers of two (the inputs stay bf16-representable) that move the magnitudes of the activations and of the
+    gradients; the key projection is scaled by 1 / x_scale so that the attention logits -- and with them the conditioning of the
+    softmax -- stay what they were (x 2^10 alone makes the softmax one-hot: an ill-conditioned problem, not a range test)."""
     from oracle import aecf_oracle as O
     from tests.helpers import hot_shape_inputs
     d = hot_shape_inputs(seed)
+    E = d["E"]
+    d["x"] = d["x"] * x_scale
+    d["w_in"] = d["w_in"].clone()
+    d["w_in"][E:2 * E] *= 1.0 / x_scale
+    d["dy"] = d["dy"] * dy_scale
+    d["dwbar"] = d["dwbar"] * dy_scale
     B, H = d["B"], d["H"]
     qe = d["query"].expand(B, -1, -1)
     f = O.mha_forward(qe, d["x"], d["x"], d["w_in"], d["b_in"], d["w_out"], d["b_out"], H)
@@ -187,7 +196,8 @@ def test_bf16_precise_form_meets_1e3(case):
         assert e < BF16_TOL, (case, k, e)
 
 
-@pytest.mark.parametrize("case", ["hot_seed61", "hot_seed62", "g2_mha_bf16_e128h4m3", "g2_mha_bf16_e256h8m2"])
+@pytest.mark.parametrize("case", ["hot_seed61", "hot_seed62", "hot_seed63_tiny_grads", "hot_seed64_large_inputs", "g2_mha_bf16_e128h4m3",
+                                  "g2_mha_bf16_e256h8m2"])
 def test_hilo_weight_gradients_are_float32_accurate(case):
     """AECF_HILO_GRADS: with the weight-gradient products on bf16 hi + lo operand pairs (o, do = dy W_o and
     the pooled rows split where they are formed; the score gradient from do_hi + do_lo) the float32-STORED parameter gradients
@@ -198,7 +208,11 @@ def test_hilo_weight_gradients_are_float32_accurate(case):
     from aecf_amd import layer, _lib
     dev = _dev()
     if case.startswith("hot_"):
-        d, truth = _hot_case(int(case[len("hot_seed"):]), torch.bfloat16)
+        # (the low parts are bf16 numbers 2^-9 below their high parts: upstream gradients of 2^-40 put them near 1e-15 -- well
+        #  inside bf16's float32 exponent range -- and inputs of 2^10 keep every product finite)
+        scales = dict(x_scale=2.0 ** 10, dy_scale=1.0) if case.endswith("large_inputs") else (
+            dict(x_scale=1.0, dy_scale=2.0 ** -40) if case.endswith("tiny_grads") else {})
+        d, truth = _hot_case(int(case[len("hot_seed"):len("hot_seed") + 2]), torch.bfloat16, **scales)
     else:
         if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", case + ".npz")):
             pytest.skip("fixture not present")
